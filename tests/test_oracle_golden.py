@@ -1,0 +1,104 @@
+"""Pin the oracle (oracle/unicorn_oracle.py) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import unicorn_oracle as uo
+
+MAX_FULL = 1 << 15
+
+
+def sample(t):
+    a = t.detach().float().contiguous().numpy().reshape(-1)
+    if a.size <= MAX_FULL:
+        return a
+    return a[np.linspace(0, a.size - 1, MAX_FULL).astype(np.int64)]
+
+
+def check(g, name, t, rtol=1e-4, atol=1e-4):
+    assert tuple(g[name + "__shape"]) == tuple(t.shape), name
+    ref = g[name]
+    got = sample(t)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref).max()
+    assert err <= atol * scale + rtol * scale, "%s: max err %g (scale %g)" % (name, err, scale)
+
+
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask", "unicorn_track_large",
+                                 "unicorn_track_large_mask", "unicorn_track_large_mot_challenge"])
+def test_param_spec_matches_reference_layout(exp, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "state_spec_%s.json" % exp)))
+    spec = synth.param_spec(uo.CONFIGS[exp])
+    assert list(spec.keys()).sort() == list(ref.keys()).sort()
+    assert set(spec) == set(ref)
+    for k, v in spec.items():
+        assert list(v) == ref[k], k
+
+
+def test_msda_known_answer(golden_dir):
+    """unicorn/models/ops/test.py:24-50 (shapes, seed 3) + a bigger case with out-of-range samples."""
+    g = np.load(os.path.join(golden_dir, "msda_known_answer.npz"))
+    for sfx in ("", "2"):
+        shapes = [tuple(int(v) for v in r) for r in g["shapes" + sfx]]
+        out = uo.msda_core(torch.from_numpy(g["value" + sfx]), shapes, torch.from_numpy(g["loc" + sfx]),
+                           torch.from_numpy(g["attn" + sfx]))
+        ref = torch.from_numpy(g["out" + sfx])
+        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-6), (out - ref).abs().max()
+
+
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask"])
+def test_sot_step_matches_reference(exp, golden_dir):
+    """BASELINE.json configs[0]: tiny, 2-frame 320x320 synthetic clip, CPU."""
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "%s_320x320.npz" % exp))
+    cfg = uo.CONFIGS[exp]
+    P = synth.synth_state_dict(cfg)
+    frames, box = synth.synth_clip(320, 320, 2, seed=1)
+    with torch.no_grad():
+        st = uo.sot_init(P, cfg, frames[0], box)
+        check(g, "lbs_pre", st["lbs_pre"])
+        r = uo.sot_step(P, cfg, st, frames[1])
+        for i in range(3):
+            check(g, "fpn%d" % i, r["fpn"][i])
+        check(g, "seq_feat", r["seq"]["feat"])
+        check(g, "seq_pos", r["seq"]["pos"])
+        check(g, "feat_pre", r["feat_pre"])
+        check(g, "feat_cur", r["feat_cur"])
+        check(g, "embed_pre", r["embed_pre"])
+        check(g, "embed_cur", r["embed_cur"])
+        check(g, "coarse", r["coarse"], atol=1e-5)
+        pri = uo.prior_pyramid(r["coarse"])
+        check(g, "prior16", pri[1], atol=1e-5)
+        check(g, "prior32", pri[2], atol=1e-5)
+        if cfg.mask:
+            names = ["head_out", "locations", "dyn_params", "fpn_levels", "mask_feats", "up_masks"]
+            for n, t in zip(names, r["head"]):
+                check(g, n, t)
+            head = tuple(t.clone() for t in r["head"])
+            det, masks = uo.postprocess_inst(cfg, head, 1, 0.001, 0.65)
+            assert det.shape[0] == int(g["n_det_sot"][0])
+            check(g, "det_sot", det[:8])
+            bits = np.packbits((masks[:8] > 0.5).numpy().astype(np.uint8).reshape(-1))
+            ref_bits = g["mask_sot_bits"]
+            diff = np.unpackbits(bits ^ ref_bits).sum()
+            assert diff <= 1e-5 * ref_bits.size * 8, diff
+            check(g, "mask_sot", masks[:8][:, :, ::8, ::8])
+        else:
+            check(g, "head_out", r["head"])
+            det = uo.postprocess(r["head"].clone(), 1, 0.001, 0.65)[0]
+            assert det.shape[0] == int(g["n_det_sot"][0])
+            check(g, "det_sot", det[:64])
+        whole, _, _ = uo.mot_whole(P, cfg, frames[1])
+        who = whole[0] if cfg.mask else whole
+        check(g, "whole_out", who)
+        det = uo.postprocess(who.clone(), cfg.num_classes, 0.01, 0.65)[0]
+        assert (0 if det is None else det.shape[0]) == int(g["n_det_mot"][0])
+        if "det_mot" in g.files:
+            check(g, "det_mot", det[:64])
+            emb = uo.sample_instance_embeddings(r["embed_cur"], det[:16, :4])
+            check(g, "inst_embed", emb)
