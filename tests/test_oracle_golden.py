@@ -96,7 +96,7 @@ def test_sot_step_matches_reference(exp, golden_dir):
         whole, _, _ = uo.mot_whole(P, cfg, frames[1])
         who = whole[0] if cfg.mask else whole
         check(g, "whole_out", who)
-        det = uo.postprocess(who.clone(), cfg.num_classes, 0.01, 0.65)[0]
+        det = uo.postprocess(who.clone(), cfg.num_classes, 0.0005, 0.65)[0]
         assert (0 if det is None else det.shape[0]) == int(g["n_det_mot"][0])
         if "det_mot" in g.files:
             check(g, "det_mot", det[:64])
