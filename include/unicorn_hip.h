@@ -1,0 +1,138 @@
+/* libunicorn_hip.so — C-ABI of the MI355X-native Unicorn inference hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  The caller
+ * (Python/ctypes in unicorn_amd/, or any other host) owns every input/output buffer (device memory,
+ * e.g. torch.Tensor.data_ptr()); the library owns only an opaque uni_ctx holding re-packed weights and
+ * its scratch workspace.  Every call is asynchronous on the hipStream_t passed in (no hidden sync), and
+ * thread-compatible (one ctx per stream / process).  Return 0 on success, <0 on error
+ * (uni_last_error() gives the message).
+ *
+ * Activation layout: NHWC ("channels_last"), fp32 at the API, i.e. a (1,C,H,W) torch tensor with
+ * channels_last strides is passed as-is.  Images enter as the reference's NCHW fp32 0-255 BGR tensor.
+ *
+ * What each entry point replaces in the reference (paths relative to MasterBin-IIAU/Unicorn):
+ *   uni_msda_fwd            MultiScaleDeformableAttention.ms_deform_attn_forward
+ *                           (unicorn/models/ops/src/vision.cpp:13-16, ops/src/ms_deform_attn.h:19-38,
+ *                            ops/src/cuda/ms_deform_attn_cuda.cu:20-80)
+ *   uni_corr_softmax_pv     simi = E_ref^T E_cur; softmax(dim=0); values @ trans
+ *                           (external/lib/test/tracker/unicorn_sot.py:95-100, unicorn_vos.py:166-181)
+ *   uni_backbone_fpn        Unicorn.forward(mode="backbone") (unicorn/models/unicorn.py:231-258;
+ *                            backbone/convnext.py:141-154, backbone/yolo_pafpn_new.py:113-161)
+ *   uni_interaction         Unicorn.forward(mode="interaction") (unicorn.py:260-276,
+ *                            deformable_transformer.py:58-131, ops/modules/ms_deform_attn.py:78-115)
+ *   uni_upsample            Unicorn.forward(mode="upsample") (unicorn.py:41-44,311-313)
+ *   uni_head                UnicornHead.forward / UnicornHeadMask.forward, eval branch
+ *                           (unicorn_head.py:249-336,430-482; unicorn_head_mask.py:280-372,451-519;
+ *                            condinst/mask_branch.py:77-99,158-162)
+ *   uni_condinst_masks      DynamicMaskHead.__call__ + aligned_bilinear(d_rate)
+ *                           (condinst/dynamic_mask_head.py:172-225; utils/boxes.py:138-146)
+ *   uni_prior_pyramid       F.interpolate(coarse, 1/2 | 1/4, bilinear) (unicorn_sot.py:103-105)
+ *   uni_label_map_s8        get_label_map + F.interpolate(1/8) (unicorn_sot.py:52-53,128-139)
+ *   uni_sample_embeddings   per-box F.grid_sample of the embedding map (evaluators/mot_evaluator.py:1024-1034)
+ *   uni_pos_embed           PositionEmbeddingLearned.forward (+ identity bicubic) (position_encoding.py:25-36,
+ *                            unicorn.py:248-250)
+ *   low-level ops (uni_gemm_bf16, uni_layernorm, uni_dwconv7_ln, uni_groupnorm_act, uni_stem)
+ *                           building blocks exported for the kernel parity tests.
+ */
+#ifndef UNICORN_HIP_H
+#define UNICORN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uni_ctx uni_ctx;
+typedef void* uni_stream_t; /* hipStream_t */
+
+/* Network shape, mirrors exp/unicorn_track.py:31-113 + exps/default/*.py */
+typedef struct uni_model_cfg {
+    int32_t dims[4];     /* ConvNeXt stage widths: tiny 96,192,384,768 / large 192,384,768,1536 */
+    int32_t depths[4];   /* 3,3,9,3 / 3,3,27,3 */
+    int32_t num_classes; /* MOT classes (8 BDD100K, 1 MOT17) */
+    int32_t mask;        /* 1 = UnicornHeadMask (+ mask branch, controllers) */
+    int32_t n_layer_att; /* 3 */
+    int32_t embed_dim;   /* 128 */
+    int32_t up_rate;     /* 8 // d_rate (4) */
+    int32_t d_rate;      /* 2 */
+} uni_model_cfg;
+
+const char* uni_last_error(void);
+int uni_version(void);
+
+/* ---- context / weights ------------------------------------------------------------------------- */
+uni_ctx* uni_ctx_create(int device_id, const uni_model_cfg* cfg);
+void uni_ctx_destroy(uni_ctx* ctx);
+/* Register one reference state-dict tensor (fp32, HOST memory, reference layout e.g. OIHW).  Unknown
+ * names are ignored (returns 1), like load_state_dict(strict=False). */
+int uni_ctx_load_param(uni_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* Re-pack weights for the device (NHWC / [N][K] bf16, layer-scale folded).  *n_missing = parameters the
+ * configured network needs but which were never loaded (left at zero). */
+int uni_ctx_finalize(uni_ctx* ctx, int* n_missing);
+/* name of the i-th missing parameter after finalize (NULL when out of range) */
+const char* uni_ctx_missing_name(uni_ctx* ctx, int i);
+/* Pre-size the scratch workspace for an (H,W) input (optional; grows on demand otherwise). */
+int uni_ctx_reserve(uni_ctx* ctx, int H, int W);
+
+/* ---- stage entry points (one per Unicorn.forward mode) ----------------------------------------------- */
+/* img: (1,3,H,W) fp32 NCHW.  fpn{0,1,2}: NHWC fp32 (H/8,W/8,C1), (H/16,W/16,C2), (H/32,W/32,C3).
+ * feat16: NHWC fp32 (H/16,W/16,C2) = seq_dict["feat"].  H, W multiples of 32. */
+int uni_backbone_fpn(uni_ctx* ctx, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2,
+                     float* feat16, uni_stream_t stream);
+/* feat_*: NHWC fp32 (h,w,C2); pos_*: NHWC fp32 (h,w,256); out_*: NHWC fp32 (h,w,256). */
+int uni_interaction(uni_ctx* ctx, const float* feat_ref, const float* pos_ref, const float* feat_cur,
+                    const float* pos_cur, int h, int w, float* out_ref, float* out_cur, uni_stream_t stream);
+/* feat: NHWC fp32 (h,w,256) -> embed: NHWC fp32 (2h,2w,embed_dim). */
+int uni_upsample(uni_ctx* ctx, const float* feat, int h, int w, float* embed, uni_stream_t stream);
+/* fpn*: as produced by uni_backbone_fpn for an (H,W) image; prior*: (H/8*W/8), (H/16*W/16), (H/32*W/32) fp32
+ * (K=1 prior per level).  mode: 0 = "sot", 1 = "mot".  out: (A, 5+nc) fp32 decoded, A = sum of level sizes,
+ * nc = 1 (sot) or num_classes (mot).  Mask models additionally fill dyn_params (A,169), mask_feats
+ * (H/8,W/8,8) NHWC and up_masks (H/8,W/8,9*up_rate^2) NHWC (pass NULL for box-only models). */
+int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
+             const float* prior16, const float* prior32, int H, int W, int mode, float* out, float* dyn_params,
+             float* mask_feats, float* up_masks, uni_stream_t stream);
+int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream);
+
+/* ---- context-free operators ------------------------------------------------------------------------- */
+/* value [N,S,M,D] fp32, spatial_shapes [L,2] int64 HOST, level_start_index [L] int64 HOST,
+ * sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P] -> out [N,Lq,M*D]. */
+int uni_msda_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                 const float* sampling_loc, const float* attn_weight, float* out, int N, int S, int M, int D, int Lq,
+                 int L, int P, uni_stream_t stream);
+/* e_ref [R,128], e_cur [Q,128] fp32 row-major (NHWC embedding maps), values [K,R] -> out [K,Q].
+ * precision 0 = exact fp32 MFMA.  workspace: device scratch of >= uni_corr_workspace_bytes bytes. */
+size_t uni_corr_workspace_bytes(int R, int Q, int K);
+int uni_corr_softmax_pv(const float* e_ref, const float* e_cur, const float* values, float* out, int R, int Q, int D,
+                        int K, int precision, void* workspace, size_t workspace_bytes, uni_stream_t stream);
+int uni_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, uni_stream_t stream);
+int uni_label_map_s8(const float* box_xyxy_dev, float* out, int H, int W, uni_stream_t stream);
+int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const float* boxes_xyxy, int ld_boxes, int n,
+                          float stride, float* out, uni_stream_t stream);
+/* mask_feats (H8,W8,8), up_masks (H8,W8,9*r*r) NHWC fp32; params (n,169) row stride ldp; inst_loc (n,2);
+ * inst_lvl (n) int32 -> out (n, d_rate*r*H8, d_rate*r*W8) sigmoid scores.  workspace >= n*H8*W8*(1+r*r)*4 bytes */
+int uni_condinst_masks(const float* mask_feats, const float* up_masks, const float* params, int ldp,
+                       const float* inst_loc, const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate,
+                       float* out, void* workspace, size_t workspace_bytes, uni_stream_t stream);
+
+/* ---- low-level building blocks (exported for kernel parity tests) --------------------------------------- */
+/* out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+res).  A: bf16 NHWC map (Hin,Win,Cin) row stride lda.
+ * w_packed: [roundup(N,128)][roundup(K,64)] bf16, K order (ky,kx,c) (see uni_pack_weight). */
+int uni_pack_weight(const float* w_oihw_host, int N, int Cin, int KH, int KW, uint16_t* out_host_bf16);
+int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, int N, int Hin, int Win, int Cin, int KH,
+                  int KW, int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF,
+                  int ldf, uint16_t* outB, int ldb, double* gn_stats, int cpg, int force_cfg, uni_stream_t stream);
+int uni_cast_bf16(const float* x, int ldx, uint16_t* out, int ldo, int M, int C, uni_stream_t stream);
+int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, float* outF,
+                  uint16_t* outB, uni_stream_t stream);
+int uni_dwconv7_ln(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta,
+                   float eps, int H, int W, int C, uint16_t* out_bf16, uni_stream_t stream);
+int uni_groupnorm_act(const float* x, const double* stats, const float* gamma, const float* beta, float eps, int M,
+                      int C, int G, int act, float* outF, uint16_t* outB, uni_stream_t stream);
+int uni_stem(const float* img, int H, int W, const float* w48c, const float* bias, const float* gamma,
+             const float* beta, int C, float* out_nhwc, uni_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,216 @@
+"""End-to-end parity of the HIP path (through unicorn_amd's reference-shaped Python API -> C-ABI) against
+(a) golden vectors produced by the REAL reference (tiny, 320x320) and (b) the CPU oracle at 800x1280.
+
+Tolerances (floating point path, bf16 MFMA operands / fp32 accumulate / fp32 residual stream, fp32 correlation):
+  feature maps      relative L2 error <= 2e-2
+  embeddings        per-pixel cosine >= 1 - 1e-3 (mean >= 1 - 1e-4)        [north_star: cosine within 1e-4]
+  propagated prior  max abs error <= 2e-2 (values in [0,1])
+  boxes             IoU(hip, oracle) >= 0.99 on the top-scored anchors (mean >= 0.999)
+The measured values are written to gpurun_out/parity_metrics.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import synth  # noqa: E402
+import unicorn_oracle as uo  # noqa: E402
+
+MAX_FULL = 1 << 15
+METRICS = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dump():
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_metrics.json"), "w") as f:
+        json.dump(METRICS, f, indent=1)
+
+
+def sample(t):
+    a = t.detach().float().cpu().contiguous().numpy().reshape(-1)
+    if a.size <= MAX_FULL:
+        return a
+    return a[np.linspace(0, a.size - 1, MAX_FULL).astype(np.int64)]
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def cos_per_pixel(a, b):
+    """a,b (1,C,H,W) -> per-pixel cosine"""
+    a, b = a.float().cpu().flatten(2)[0].double(), b.float().cpu().flatten(2)[0].double()
+    return ((a * b).sum(0) / (a.norm(dim=0) * b.norm(dim=0)).clamp_min(1e-30)).numpy()
+
+
+def box_iou_pairs(a, b):
+    """cxcywh rows -> IoU of matching rows"""
+    ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+    bx1, by1, bx2, by2 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    iw = (torch.min(ax2, bx2) - torch.max(ax1, bx1)).clamp(min=0)
+    ih = (torch.min(ay2, by2) - torch.max(ay1, by1)).clamp(min=0)
+    inter = iw * ih
+    return inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
+
+
+def build(name):
+    from unicorn_amd.models import Unicorn
+    cfg = uo.CONFIGS[name]
+    P = synth.synth_state_dict(cfg)
+    m = Unicorn(name).cuda()
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not missing, missing[:5]
+    return m.eval(), cfg, P
+
+
+def hip_sot_step(m, cfg, frames, box):
+    """the driver logic of external/lib/test/tracker/unicorn_sot.py:39-55,78-108 on the drop-in API"""
+    from unicorn_amd.ops import corr_softmax_pv, label_map_s8, prior_pyramid
+    H, W = frames[0].shape[-2:]
+    with torch.no_grad():
+        _, d_pre = m(imgs=frames[0].cuda(), mode="backbone")
+        lbs = label_map_s8(box, H, W, "cuda")
+        fpn, d_cur = m(imgs=frames[1].cuda(), mode="backbone")
+        f_pre, f_cur = m(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
+        e_pre, e_cur = m(feat=f_pre, mode="upsample"), m(feat=f_cur, mode="upsample")
+        pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), lbs)
+        coarse = pred.view(1, -1, d_cur["h"] * 2, d_cur["w"] * 2)
+        pri = prior_pyramid(coarse)
+        head = m.head(fpn, pri, mode="sot")
+    torch.cuda.synchronize()
+    return dict(lbs=lbs, fpn=fpn, seq=d_cur, feat_pre=f_pre, feat_cur=f_cur, embed_pre=e_pre, embed_cur=e_cur, coarse=coarse,
+                pri=pri, head=head)
+
+
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask"])
+def test_tiny_320_vs_reference_golden(exp, golden_dir):
+    """BASELINE.json configs[0] shapes; expected values come from the real reference (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "%s_320x320.npz" % exp))
+    m, cfg, P = build(exp)
+    frames, box = synth.synth_clip(320, 320, 2, seed=1)
+    r = hip_sot_step(m, cfg, frames, box)
+    met = {}
+    assert np.array_equal(sample(r["lbs"]), g["lbs_pre"])
+    for i in range(3):
+        met["fpn%d" % i] = rel_l2(sample(r["fpn"][i]), g["fpn%d" % i])
+    met["seq_feat"] = rel_l2(sample(r["seq"]["feat"]), g["seq_feat"])
+    met["seq_pos"] = rel_l2(sample(r["seq"]["pos"]), g["seq_pos"])
+    met["feat_pre"] = rel_l2(sample(r["feat_pre"]), g["feat_pre"])
+    met["feat_cur"] = rel_l2(sample(r["feat_cur"]), g["feat_cur"])
+    met["embed_pre"] = rel_l2(sample(r["embed_pre"]), g["embed_pre"])
+    met["embed_cur"] = rel_l2(sample(r["embed_cur"]), g["embed_cur"])
+    met["coarse_maxabs"] = float(np.abs(sample(r["coarse"]) - g["coarse"]).max())
+    head = r["head"][0] if cfg.mask else r["head"]
+    hg = torch.from_numpy(g["head_out"]).reshape(tuple(g["head_out__shape"]))[0]
+    hh = head[0].cpu()
+    score = hg[:, 4] * hg[:, 5]
+    top = torch.argsort(score, descending=True)[:200]
+    iou = box_iou_pairs(hh[top, :4], hg[top, :4])
+    met["box_iou_min_top200"] = float(iou.min())
+    met["box_iou_mean_top200"] = float(iou.mean())
+    met["score_relerr_top200"] = float(((hh[top, 4] * hh[top, 5] - score[top]).abs() / score[top]).max())
+    if cfg.mask:
+        for n, t in zip(["dyn_params", "mask_feats", "up_masks"], [r["head"][2], r["head"][4], r["head"][5]]):
+            met[n] = rel_l2(sample(t), g[n])
+        assert np.allclose(sample(r["head"][1]), g["locations"])
+        assert np.array_equal(sample(r["head"][3]), g["fpn_levels"])
+    METRICS["golden_" + exp] = met
+    _dump()
+    assert met["seq_pos"] < 1e-5
+    for k in ("fpn0", "fpn1", "fpn2", "seq_feat", "feat_pre", "feat_cur", "embed_pre", "embed_cur"):
+        assert met[k] < 2e-2, (k, met[k])
+    assert met["coarse_maxabs"] < 2e-2
+    assert met["box_iou_min_top200"] > 0.99 and met["box_iou_mean_top200"] > 0.999
+    assert met["score_relerr_top200"] < 0.1
+
+
+def _vs_oracle(exp, H, W, tag):
+    m, cfg, P = build(exp)
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    r = hip_sot_step(m, cfg, frames, box)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        st = uo.sot_init(P, cfg, frames[0], box)
+        o = uo.sot_step(P, cfg, st, frames[1])
+    met = {}
+    assert torch.equal(r["lbs"].cpu(), st["lbs_pre"])
+    for i in range(3):
+        met["fpn%d" % i] = rel_l2(r["fpn"][i].cpu().contiguous().numpy(), o["fpn"][i].numpy())
+    met["seq_feat"] = rel_l2(r["seq"]["feat"].cpu().contiguous().numpy(), o["seq"]["feat"].numpy())
+    met["feat_cur"] = rel_l2(r["feat_cur"].cpu().contiguous().numpy(), o["feat_cur"].numpy())
+    for k in ("embed_pre", "embed_cur"):
+        c = cos_per_pixel(r[k], o[k])
+        met[k + "_cos_min"] = float(c.min())
+        met[k + "_cos_mean"] = float(c.mean())
+        met[k + "_rel_l2"] = rel_l2(r[k].cpu().contiguous().numpy(), o[k].numpy())
+    met["coarse_maxabs"] = float((r["coarse"].cpu() - o["coarse"]).abs().max())
+    # correlation kernel in isolation: HIP corr on the ORACLE's embeddings must match to fp32 round-off
+    from unicorn_amd.ops import corr_softmax_pv
+    iso = corr_softmax_pv(o["embed_pre"].flatten(-2)[0].cuda(), o["embed_cur"].flatten(-2)[0].cuda(), st["lbs_pre"].cuda())
+    met["corr_isolated_maxabs"] = float((iso.cpu() - o["coarse"].flatten(1)).abs().max())
+    ho = o["head"][0] if cfg.mask else o["head"]
+    hh = (r["head"][0] if cfg.mask else r["head"]).cpu()
+    score = ho[0, :, 4] * ho[0, :, 5]
+    top = torch.argsort(score, descending=True)[:500]
+    iou = box_iou_pairs(hh[0, top, :4], ho[0, top, :4])
+    met["box_iou_min_top500"] = float(iou.min())
+    met["box_iou_mean_top500"] = float(iou.mean())
+    met["box_iou_min_all"] = float(box_iou_pairs(hh[0, :, :4], ho[0, :, :4]).min())
+    # the SOT decision (unicorn_sot.py:62-76): NMS, take the first box
+    det_o = uo.postprocess(ho.clone(), 1, 0.001, 0.65)[0]
+    det_h = uo.postprocess(hh.clone(), 1, 0.001, 0.65)[0]     # same post-processing on both (isolates the network)
+    if det_o is not None and det_h is not None:
+        a, b = det_h[:1, :4], det_o[:1, :4]
+        cx = lambda t: torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], 1)
+        met["sot_box_iou"] = float(box_iou_pairs(cx(a), cx(b))[0])
+    if cfg.mask:
+        met["dyn_params"] = rel_l2(r["head"][2].cpu().numpy(), o["head"][2].numpy())
+        met["mask_feats"] = rel_l2(r["head"][4].cpu().contiguous().numpy(), o["head"][4].numpy())
+        met["up_masks"] = rel_l2(r["head"][5].cpu().contiguous().numpy(), o["head"][5].numpy())
+    METRICS[tag] = met
+    _dump()
+    return met
+
+
+def _assert_bar(met):
+    for k in ("fpn0", "fpn1", "fpn2", "seq_feat", "feat_cur"):
+        assert met[k] < 2e-2, (k, met[k])
+    assert met["embed_cur_cos_min"] > 1 - 1e-3 and met["embed_cur_cos_mean"] > 1 - 1e-4, met
+    assert met["embed_pre_cos_min"] > 1 - 1e-3 and met["embed_pre_cos_mean"] > 1 - 1e-4, met
+    assert met["corr_isolated_maxabs"] < 2e-5, met
+    assert met["coarse_maxabs"] < 2e-2, met
+    assert met["box_iou_min_top500"] > 0.99 and met["box_iou_mean_top500"] > 0.999, met
+    if "sot_box_iou" in met:
+        assert met["sot_box_iou"] > 0.99, met
+
+
+def test_tiny_sot_800x1280_vs_oracle():
+    """BASELINE.json configs[1]: unicorn_track_tiny SOT 800x1280 (bf16 backbone + fp32 correlation)."""
+    _assert_bar(_vs_oracle("unicorn_track_tiny", 800, 1280, "tiny_sot_800x1280"))
+
+
+def test_tiny_ragged_size_vs_oracle():
+    """non-square, not a multiple of 64/128 anywhere: 352x608 (strips, tiles and splits all ragged)."""
+    _assert_bar(_vs_oracle("unicorn_track_tiny_mask", 352, 608, "tiny_mask_352x608"))
+
+
+def test_whole_mot_mode_matches_head_with_zero_priors():
+    m, cfg, P = build("unicorn_track_tiny")
+    frames, _ = synth.synth_clip(320, 320, 2, seed=1)
+    with torch.no_grad():
+        out, seq = m(frames[1].cuda())
+        whole_o, _, _ = uo.mot_whole(P, cfg, frames[1])
+    assert out.shape == (1, 2100, 13) and seq["feat"].shape == (1, 384, 20, 20)
+    score = whole_o[0, :, 4] * whole_o[0, :, 5:].max(1)[0]
+    top = torch.argsort(score, descending=True)[:200]
+    iou = box_iou_pairs(out[0].cpu()[top, :4], whole_o[0, top, :4])
+    assert iou.min() > 0.99
+    with pytest.raises(ValueError):
+        m.head(None, None, mode="bogus")
+    with pytest.raises(ValueError):
+        m(imgs=frames[1].cuda(), mode="nonsense")

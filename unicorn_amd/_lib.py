@@ -1,0 +1,87 @@
+"""ctypes binding of libunicorn_hip.so (the reference-side stub a maintainer would add)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunicorn_hip.so")
+
+c_f = C.c_void_p   # device pointers travel as void*
+c_i = C.c_int
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 4), ("depths", C.c_int32 * 4), ("num_classes", C.c_int32), ("mask", C.c_int32),
+                ("n_layer_att", C.c_int32), ("embed_dim", C.c_int32), ("up_rate", C.c_int32), ("d_rate", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/unicorn_hip.h
+PROTOS = {
+    "uni_last_error": (C.c_char_p, []),
+    "uni_version": (c_i, []),
+    "uni_ctx_create": (C.c_void_p, [c_i, C.POINTER(ModelCfg)]),
+    "uni_ctx_destroy": (None, [C.c_void_p]),
+    "uni_ctx_load_param": (c_i, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), c_i]),
+    "uni_ctx_finalize": (c_i, [C.c_void_p, C.POINTER(c_i)]),
+    "uni_ctx_missing_name": (C.c_char_p, [C.c_void_p, c_i]),
+    "uni_ctx_reserve": (c_i, [C.c_void_p, c_i, c_i]),
+    "uni_backbone_fpn": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
+    "uni_interaction": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, C.c_void_p]),
+    "uni_upsample": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, C.c_void_p]),
+    "uni_head": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
+    "uni_pos_embed": (c_i, [C.c_void_p, c_i, c_i, c_f, C.c_void_p]),
+    "uni_msda_fwd": (c_i, [c_f, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                           C.c_void_p]),
+    "uni_corr_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i]),
+    "uni_corr_softmax_pv": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uni_prior_pyramid": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
+    "uni_label_map_s8": (c_i, [c_f, c_f, c_i, c_i, C.c_void_p]),
+    "uni_sample_embeddings": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, C.c_float, c_f, C.c_void_p]),
+    "uni_condinst_masks": (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uni_pack_weight": (c_i, [C.c_void_p, c_i, c_i, c_i, c_i, C.c_void_p]),
+    "uni_gemm_bf16": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i,
+                            c_f, c_i, c_i, C.c_void_p]),
+    "uni_cast_bf16": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, C.c_void_p]),
+    "uni_layernorm": (c_i, [c_f, c_i, c_f, c_f, C.c_float, c_i, c_i, c_f, c_f, C.c_void_p]),
+    "uni_dwconv7_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_f, C.c_void_p]),
+    "uni_groupnorm_act": (c_i, [c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
+    "uni_stem": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, C.c_void_p]),
+}
+
+_lib = None
+
+
+class UnicornHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libunicorn_hip.so (built by __graft_entry__.build() / unicorn_amd/csrc/build.sh).  No fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UnicornHipError(
+                "libunicorn_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU/PyTorch fallback for the Unicorn hot path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOS.items():
+            fn = getattr(L, name)      # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().uni_last_error()
+        raise UnicornHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,194 @@
+// extern "C" surface of libunicorn_hip.so (declared in include/unicorn_hip.h).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "engine.h"
+
+static thread_local char g_err[1024] = "";
+void uni_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+static inline hipStream_t S(uni_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static int post_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { uni_set_error("kernel launch failed: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+#define API(expr) do { int _rc = (expr); if (_rc) return _rc; return post_launch(); } while (0)
+
+extern "C" {
+
+const char* uni_last_error(void) { return g_err; }
+int uni_version(void) { return 1; }
+
+uni_ctx* uni_ctx_create(int device_id, const uni_model_cfg* cfg) {
+    if (!cfg) { uni_set_error("cfg is NULL"); return nullptr; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) {
+        uni_set_error("no HIP device %d (count %d)", device_id, n);
+        return nullptr;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (cfg->dims[i] <= 0 || cfg->dims[i] % 8 || cfg->depths[i] < 0) { uni_set_error("bad cfg dims/depths"); return nullptr; }
+    if (cfg->embed_dim != 128) { uni_set_error("embed_dim %d unsupported (128)", cfg->embed_dim); return nullptr; }
+    uni_ctx* c = new uni_ctx();
+    c->device = device_id;
+    c->cfg = *cfg;
+    return c;
+}
+void uni_ctx_destroy(uni_ctx* ctx) { engine_destroy(ctx); }
+
+int uni_ctx_load_param(uni_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    UNI_REQUIRE(ctx && name && host_data && (shape || ndim == 0), "load_param: NULL argument");
+    UNI_REQUIRE(!ctx->finalized, "load_param after finalize");
+    HostParam p;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { p.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    p.data.assign(host_data, host_data + n);
+    ctx->host[name] = std::move(p);
+    return 0;
+}
+int uni_ctx_finalize(uni_ctx* ctx, int* n_missing) {
+    UNI_REQUIRE(ctx, "ctx is NULL");
+    UNI_REQUIRE(!ctx->finalized, "already finalized");
+    int rc = engine_finalize(ctx);
+    if (n_missing) *n_missing = (int)ctx->missing.size();
+    return rc;
+}
+const char* uni_ctx_missing_name(uni_ctx* ctx, int i) {
+    if (!ctx || i < 0 || i >= (int)ctx->missing.size()) return nullptr;
+    return ctx->missing[i].c_str();
+}
+int uni_ctx_reserve(uni_ctx* ctx, int H, int W) {
+    UNI_REQUIRE(ctx && ctx->finalized, "context not finalized");
+    return engine_reserve(ctx, H, W);
+}
+
+int uni_backbone_fpn(uni_ctx* ctx, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
+                     uni_stream_t stream) {
+    UNI_REQUIRE(ctx && img && fpn0 && fpn1 && fpn2 && feat16, "backbone_fpn: NULL argument");
+    API(engine_backbone_fpn(ctx, img, H, W, fpn0, fpn1, fpn2, feat16, S(stream)));
+}
+int uni_interaction(uni_ctx* ctx, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,
+                    int h, int w, float* out_ref, float* out_cur, uni_stream_t stream) {
+    UNI_REQUIRE(ctx && feat_ref && pos_ref && feat_cur && pos_cur && out_ref && out_cur, "interaction: NULL argument");
+    UNI_REQUIRE(h > 0 && w > 0, "interaction: h=%d w=%d", h, w);
+    API(engine_interaction(ctx, feat_ref, pos_ref, feat_cur, pos_cur, h, w, out_ref, out_cur, S(stream)));
+}
+int uni_upsample(uni_ctx* ctx, const float* feat, int h, int w, float* embed, uni_stream_t stream) {
+    UNI_REQUIRE(ctx && feat && embed && h > 0 && w > 0, "upsample: bad argument");
+    API(engine_upsample(ctx, feat, h, w, embed, S(stream)));
+}
+int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8, const float* prior16,
+             const float* prior32, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
+             uni_stream_t stream) {
+    UNI_REQUIRE(ctx && fpn0 && fpn1 && fpn2 && prior8 && prior16 && prior32 && out, "head: NULL argument");
+    API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
+}
+int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream) {
+    UNI_REQUIRE(ctx && out_nhwc && h > 0 && w > 0, "pos_embed: bad argument");
+    API(engine_pos_embed(ctx, h, w, out_nhwc, S(stream)));
+}
+
+int uni_msda_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* sampling_loc,
+                 const float* attn_weight, float* out, int N, int S_, int M, int D, int Lq, int L, int P, uni_stream_t stream) {
+    UNI_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out, "msda: NULL argument");
+    API(launch_msda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S_, M, D, Lq, L, P, S(stream)));
+}
+size_t uni_corr_workspace_bytes(int R, int Q, int K) { return corr_workspace_bytes(R, Q, K); }
+int uni_corr_softmax_pv(const float* e_ref, const float* e_cur, const float* values, float* out, int R, int Q, int D, int K,
+                        int precision, void* workspace, size_t workspace_bytes, uni_stream_t stream) {
+    UNI_REQUIRE(e_ref && e_cur && values && out && workspace, "corr: NULL argument");
+    API(launch_corr(e_ref, e_cur, values, out, R, Q, D, K, precision, workspace, workspace_bytes, S(stream)));
+}
+int uni_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, uni_stream_t stream) {
+    UNI_REQUIRE(p8 && p16 && p32, "prior_pyramid: NULL argument");
+    API(launch_prior_pyramid(p8, p16, p32, K, H8, W8, S(stream)));
+}
+int uni_label_map_s8(const float* box_xyxy_dev, float* out, int H, int W, uni_stream_t stream) {
+    UNI_REQUIRE(box_xyxy_dev && out && H % 8 == 0 && W % 8 == 0, "label_map: bad argument");
+    API(launch_label_map_s8(box_xyxy_dev, out, H, W, S(stream)));
+}
+int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const float* boxes_xyxy, int ld_boxes, int n, float stride,
+                          float* out, uni_stream_t stream) {
+    UNI_REQUIRE(embed_nhwc && (n == 0 || (boxes_xyxy && out)), "sample_embeddings: NULL argument");
+    API(launch_sample_embed(embed_nhwc, H8, W8, C, boxes_xyxy, ld_boxes, n, stride, out, S(stream)));
+}
+int uni_condinst_masks(const float* mask_feats, const float* up_masks, const float* params, int ldp, const float* inst_loc,
+                       const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate, float* out, void* workspace,
+                       size_t workspace_bytes, uni_stream_t stream) {
+    if (n == 0) return 0;
+    UNI_REQUIRE(mask_feats && up_masks && params && inst_loc && inst_lvl && out && workspace, "condinst: NULL argument");
+    const size_t need = (size_t)n * H8 * W8 * (1 + up_rate * up_rate) * sizeof(float);
+    UNI_REQUIRE(workspace_bytes >= need, "condinst: workspace %zu < %zu", workspace_bytes, need);
+    CondInstArgs a;
+    a.mask_feats = mask_feats; a.up_masks = up_masks; a.params = params; a.ldp = ldp; a.inst_loc = inst_loc; a.inst_lvl = inst_lvl;
+    a.n = n; a.H = H8; a.W = W8; a.r = up_rate; a.d_rate = d_rate;
+    a.logits_ws = reinterpret_cast<float*>(workspace);
+    a.coarse_ws = a.logits_ws + (size_t)n * H8 * W8;
+    a.out = out;
+    API(launch_condinst(a, S(stream)));
+}
+
+int uni_pack_weight(const float* w, int N, int Cin, int KH, int KW, uint16_t* out) {
+    UNI_REQUIRE(w && out && N > 0 && Cin > 0, "pack_weight: bad argument");
+    pack_weight_host(w, N, Cin, KH, KW, nullptr, out, cdiv(N, 128) * 128, cdiv(Cin * KH * KW, 64) * 64);
+    return 0;
+}
+int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, int N, int Hin, int Win, int Cin, int KH, int KW,
+                  int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF, int ldf,
+                  uint16_t* outB, int ldb, double* gn_stats, int cpg, int force_cfg, uni_stream_t stream) {
+    UNI_REQUIRE(A && w_packed && (outF || outB), "gemm: NULL argument");
+    GemmArgs g;
+    g.A = reinterpret_cast<const bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16*>(w_packed);
+    g.N = N; g.K = Cin * KH * KW; g.Kpad = cdiv(g.K, 64) * 64;
+    g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    const int Hout = (Hin + 2 * pad - KH) / stride + 1;
+    g.Wout = (Win + 2 * pad - KW) / stride + 1;
+    g.M = Hout * g.Wout;
+    UNI_REQUIRE(g.M == M, "gemm: M=%d does not match conv geometry (%d)", M, g.M);
+    g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
+    g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
+    API(launch_gemm(g, S(stream)));
+}
+int uni_cast_bf16(const float* x, int ldx, uint16_t* out, int ldo, int M, int C, uni_stream_t stream) {
+    UNI_REQUIRE(x && out, "cast: NULL argument");
+    API(launch_cast_bf16(x, ldx, reinterpret_cast<bf16*>(out), ldo, M, C, S(stream)));
+}
+int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, float* outF, uint16_t* outB,
+                  uni_stream_t stream) {
+    UNI_REQUIRE(x && gamma && beta && (outF || outB), "layernorm: NULL argument");
+    LnArgs a;
+    a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.M = M; a.C = C;
+    a.outF = outF; a.ldf = C; a.outB = reinterpret_cast<bf16*>(outB); a.ldb = C;
+    API(launch_layernorm(a, S(stream)));
+}
+int uni_dwconv7_ln(const float* x, const float* w49c, const float* bias, const float* gamma, const float* beta, float eps, int H, int W,
+                   int C, uint16_t* out, uni_stream_t stream) {
+    UNI_REQUIRE(x && w49c && bias && gamma && beta && out, "dwconv7_ln: NULL argument");
+    DwLnArgs d;
+    d.x = x; d.w = w49c; d.bias = bias; d.gamma = gamma; d.beta = beta; d.eps = eps; d.H = H; d.W = W; d.C = C;
+    d.out = reinterpret_cast<bf16*>(out);
+    API(launch_dwconv7_ln(d, S(stream)));
+}
+int uni_groupnorm_act(const float* x, const double* stats, const float* gamma, const float* beta, float eps, int M, int C, int G,
+                      int act, float* outF, uint16_t* outB, uni_stream_t stream) {
+    UNI_REQUIRE(x && stats && gamma && beta && (outF || outB), "groupnorm: NULL argument");
+    GnApplyArgs a;
+    a.x = x; a.ldx = C; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.M = M; a.C = C; a.G = G; a.act = act;
+    a.outF = outF; a.ldf = C; a.outB = reinterpret_cast<bf16*>(outB); a.ldb = C;
+    API(launch_gn_apply(a, S(stream)));
+}
+int uni_stem(const float* img, int H, int W, const float* w48c, const float* bias, const float* gamma, const float* beta, int C,
+             float* out, uni_stream_t stream) {
+    UNI_REQUIRE(img && w48c && bias && gamma && beta && out, "stem: NULL argument");
+    StemArgs a;
+    a.img = img; a.H = H; a.W = W; a.w = w48c; a.bias = bias; a.gamma = gamma; a.beta = beta; a.C = C; a.out = out;
+    API(launch_stem(a, S(stream)));
+}
+
+}  // extern "C"

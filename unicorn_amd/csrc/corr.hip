@@ -1,0 +1,225 @@
+// K4: dense embedding correlation + softmax over the REFERENCE axis + prior propagation, fused
+// flash-style (external/lib/test/tracker/unicorn_sot.py:88-100, unicorn_vos.py:166-186):
+//     out[k][q] = sum_r V[k][r] * softmax_r( <Eref[r,:], Ecur[q,:]> )          (no 1/sqrt(d) scaling)
+// The HW x HW similarity (16000^2 at 800x1280, 1 GB in fp32) is never materialised: each wave keeps 32
+// current-frame pixels (the MFMA "B" operand, 64 VGPRs) stationary, streams 32-row reference tiles through
+// LDS, and because the MFMA accumulator gives every lane 16 reference rows of ONE query column, the
+// online-softmax reduction over the reference axis is lane-local (one cross-half shuffle at the end).
+// precision 0: exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF peak, bitwise an fmaf chain).
+// The reference axis is additionally split across blocks (flash-decoding style) to fill 256 CUs; a tiny
+// second kernel merges the (max, sum, acc) partials.
+#include "kernels.h"
+
+namespace {
+constexpr int CD = 128;      // embedding dim (unicorn.py:41-44)
+constexpr int LDA = 132;     // padded LDS row stride (floats): 16 distinct rows -> 16 distinct 16-B bank slots
+constexpr int TR = 32;       // reference rows per tile
+constexpr int QB = 128;      // query columns per block (4 waves x 32)
+
+__device__ __forceinline__ int rowof(int r, int fh) { return (r & 3) + 8 * (r >> 2) + 4 * fh; }
+
+template <int KV>
+__global__ __launch_bounds__(256, 2) void corr_f32_kernel(const float* __restrict__ eref,
+                                                          const float* __restrict__ ecur,
+                                                          const float* __restrict__ v, float* __restrict__ out,
+                                                          float* __restrict__ ws, int R, int Q, int K, int nsplit,
+                                                          int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                    // [2][TR*LDA]
+    float* Vs = smem + 2 * TR * LDA;     // [2][KV*TR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int split = blockIdx.y;
+    const int q = blockIdx.x * QB + wave * 32 + fr;
+    const int qc = q < Q ? q : Q - 1;
+
+    // stationary operand: this lane's half (fh) of the 128-d embedding of its query pixel.
+    // K-permutation: MFMA step t contracts dims {t, 64+t} (lanes <32 carry t, lanes >=32 carry 64+t).
+    float b[64];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(ecur + (size_t)qc * CD + fh * 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            f32x4 t = src[i];
+            b[4 * i] = t[0]; b[4 * i + 1] = t[1]; b[4 * i + 2] = t[2]; b[4 * i + 3] = t[3];
+        }
+    }
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+    const int ntiles = (r_end - r_begin + TR - 1) / TR;
+
+    f32x4 ga[4];
+    float gv;
+    auto gload = [&](int t) {
+        const int r0 = r_begin + t * TR;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = tid + 256 * j;
+            int row = min(r0 + (idx >> 5), R - 1);
+            ga[j] = *reinterpret_cast<const f32x4*>(eref + (size_t)row * CD + (idx & 31) * 4);
+        }
+        const int k = tid >> 5, r = r0 + (tid & 31);
+        gv = (k < K && k < KV && r < R) ? v[(size_t)k * R + r] : 0.f;
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = tid + 256 * j;
+            *reinterpret_cast<f32x4*>(As + buf * TR * LDA + (idx >> 5) * LDA + (idx & 31) * 4) = ga[j];
+        }
+        if (tid < KV * TR) Vs[buf * KV * TR + tid] = gv;
+    };
+
+    float m = -INFINITY, l = 0.f, o[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) o[k] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        const float* arow = As + buf * TR * LDA + fr * LDA + fh * 64;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 4 * i);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b[4 * i], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b[4 * i + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b[4 * i + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b[4 * i + 3], acc, 0, 0, 0);
+        }
+        // online softmax over this tile's 16 rows owned by the lane
+        const int r0 = r_begin + t * TR;
+        float sc[16], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = (r0 + rowof(r, fh) < r_end) ? acc[r] : -INFINITY;
+            tmax = fmaxf(tmax, sc[r]);
+        }
+        const float mn = fmaxf(m, tmax);
+        if (mn > -INFINITY) {   // a lane whose 16 rows are all masked (ragged tail) keeps its state
+            const float f = (m > -INFINITY) ? __expf(m - mn) : 0.f;
+            l *= f;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) o[k] *= f;
+            const float* vt = Vs + buf * KV * TR;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float pr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pr[j] = __expf(sc[4 * g + j] - mn);
+                    l += pr[j];
+                }
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(vt + k * TR + 8 * g + 4 * fh);
+                    o[k] += pr[0] * v4[0] + pr[1] * v4[1] + pr[2] * v4[2] + pr[3] * v4[3];
+                }
+            }
+            m = mn;
+        }
+        if (t + 1 < ntiles) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    // merge the two lane halves (rows 4*fh.. interleaved) of each query column
+    {
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        const float M = fmaxf(m, m2);
+        const float f1 = (m > -INFINITY) ? __expf(m - M) : 0.f;
+        const float f2 = (m2 > -INFINITY) ? __expf(m2 - M) : 0.f;
+        l = l * f1 + l2 * f2;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const float o2 = __shfl_xor(o[k], 32, 64);
+            o[k] = o[k] * f1 + o2 * f2;
+        }
+        m = M;
+    }
+    if (fh == 0 && q < Q) {
+        if (nsplit == 1) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k)
+                if (k < K) out[(size_t)k * Q + q] = o[k] / l;
+        } else {
+            float* w = ws + ((size_t)split * Q + q) * (2 + KV);
+            w[0] = m;
+            w[1] = l;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) w[2 + k] = o[k];
+        }
+    }
+}
+
+template <int KV>
+__global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int Q, int K, int nsplit) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws[((size_t)s * Q + q) * (2 + KV)]);
+    float L = 0.f, O[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) O[k] = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* w = ws + ((size_t)s * Q + q) * (2 + KV);
+        const float f = (w[0] > -INFINITY) ? __expf(w[0] - M) : 0.f;
+        L += w[1] * f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) O[k] += w[2 + k] * f;
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+        if (k < K) out[(size_t)k * Q + q] = O[k] / L;
+}
+
+int pick_nsplit(int R, int Q) {
+    int nqb = cdiv(Q, QB);
+    int ns = cdiv(512, nqb);          // aim for >= 512 blocks (2048 waves over 1024 SIMDs)
+    int maxs = R / 256;               // keep >= 8 tiles per split
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+template <int KV>
+int run(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int K, float* ws,
+        hipStream_t s) {
+    const int ns = pick_nsplit(R, Q);
+    int rps = cdiv(cdiv(R, ns), TR) * TR;
+    const int ns_eff = cdiv(R, rps);   // every split non-empty
+    size_t lds = (size_t)(2 * TR * LDA + 2 * KV * TR) * sizeof(float);
+    hipLaunchKernelGGL((corr_f32_kernel<KV>), dim3(cdiv(Q, QB), ns_eff), dim3(256), lds, s, eref, ecur, v, out, ws, R,
+                       Q, K, ns_eff, rps);
+    if (ns_eff > 1)
+        hipLaunchKernelGGL((corr_merge_kernel<KV>), dim3(cdiv(Q, 256)), dim3(256), 0, s, ws, out, Q, K, ns_eff);
+    return 0;
+}
+}  // namespace
+
+size_t corr_workspace_bytes(int R, int Q, int K) {
+    (void)K;
+    return (size_t)pick_nsplit(R, Q) * Q * (2 + 8) * sizeof(float);
+}
+
+int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,
+                int precision, void* workspace, size_t ws_bytes, hipStream_t s) {
+    UNI_REQUIRE(D == CD, "corr: embedding dim %d unsupported (128)", D);
+    UNI_REQUIRE(R > 0 && Q > 0 && K > 0, "corr: empty problem R=%d Q=%d K=%d", R, Q, K);
+    UNI_REQUIRE(precision == 0, "corr: precision %d not implemented", precision);
+    UNI_REQUIRE(ws_bytes >= corr_workspace_bytes(R, Q, K), "corr: workspace too small");
+    UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
+    float* ws = reinterpret_cast<float*>(workspace);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const int kc = K - k0 < 8 ? K - k0 : 8;
+        int rc;
+        if (kc == 1) rc = run<1>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, s);
+        else if (kc <= 4) rc = run<4>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, s);
+        else rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, s);
+        if (rc) return rc;
+    }
+    return 0;
+}

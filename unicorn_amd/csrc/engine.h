@@ -1,0 +1,62 @@
+// uni_ctx: re-packed weights + workspace of one Unicorn model instance (see engine.hip).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/unicorn_hip.h"
+#include "kernels.h"
+
+#define UNI_STATS_SLOTS 128
+
+struct HostParam { std::vector<int64_t> shape; std::vector<float> data; };
+struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, KH = 1, KW = 1, Cin = 0; };
+struct PAffine { float* g = nullptr; float* b = nullptr; };
+struct PBlock { float* dw_w = nullptr; float* dw_b = nullptr; PAffine ln; PConv pw1, pw2; int C = 0; };
+struct PBaseConv { PConv conv; PAffine gn; int k = 1, stride = 1; };
+struct PCsp { PConv c12; PAffine gn12; PBaseConv m1[3], m2[3], c3; int cin = 0, cout = 0, h = 0; };
+
+struct uni_ctx {
+    int device = 0;
+    uni_model_cfg cfg{};
+    std::map<std::string, HostParam> host;
+    std::vector<std::string> missing;
+    std::vector<float> zeros;
+    std::vector<void*> dev_allocs;
+    bool finalized = false, failed = false;
+    // ConvNeXt
+    float* stem_w = nullptr; float* stem_b = nullptr; PAffine stem_ln;
+    PAffine ds_ln[4]; PConv ds_conv[4];
+    std::vector<PBlock> blocks[4];
+    PAffine out_norm[4];
+    // PAFPN
+    PBaseConv lateral0, reduce1, bu2, bu1;
+    PCsp c3p4, c3p3, c3n3, c3n4;
+    // head
+    PBaseConv stems[3]; float* beta[3] = {nullptr, nullptr, nullptr};
+    std::vector<PBlock> att[3];
+    PConv tower0[3]; PAffine tower0_gn[3];
+    PBaseConv cls_convs[3][4], reg_convs[3][4];
+    PConv cls_pred[3], cls_pred_sot[3], regobj[3], regobj_sot[3], controllers[3];
+    PConv refine[3]; PAffine refine_gn[3]; PConv mtower[4]; PAffine mtower_gn[4]; PConv mtower_out, upm0, upm1;
+    // interaction / embedding
+    PConv bott; PAffine bott_gn; PConv value_proj, offaw, output_proj, lin1, lin2; PAffine norm1, norm2;
+    float* level_embed = nullptr; PConv up1, up3; float* pos_row = nullptr; float* pos_col = nullptr;
+    // scratch
+    char* ws = nullptr; size_t ws_cap = 0, ws_off = 0; bool ws_overflow = false;
+    double* stats = nullptr; int stats_slot = 0;
+};
+
+uint16_t f32_to_bf16_host(float f);
+void pack_weight_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, uint16_t* out, int Npad, int Kpad);
+int engine_finalize(uni_ctx* c);
+int engine_reserve(uni_ctx* c, int H, int W);
+void engine_destroy(uni_ctx* c);
+int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16, hipStream_t s);
+int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,
+                       int h, int w, float* out_ref, float* out_cur, hipStream_t s);
+int engine_upsample(uni_ctx* c, const float* feat, int h, int w, float* embed, hipStream_t s);
+int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s);
+int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8, const float* prior16,
+                const float* prior32, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
+                hipStream_t s);

@@ -1,0 +1,633 @@
+// Host-side engine: owns the re-packed weights + scratch workspace and sequences the HIP kernels for the
+// four Unicorn.forward modes (backbone / interaction / upsample / head).  No torch, no Python: this is the
+// C++ runtime behind the C-ABI in api.hip.  Every function only enqueues work on the caller's stream.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------------
+// bf16 helpers (host)
+// ------------------------------------------------------------------------------------------------
+uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+void pack_weight_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, uint16_t* out, int Npad,
+                      int Kpad) {
+    // OIHW fp32 -> [Npad][Kpad] bf16 with k = (ky*KW + kx)*Cin + c, zero padded
+    const int K = KH * KW * Cin;
+    memset(out, 0, (size_t)Npad * Kpad * sizeof(uint16_t));
+    for (int n = 0; n < N; ++n) {
+        const float sc = row_scale ? row_scale[n] : 1.f;
+        uint16_t* o = out + (size_t)n * Kpad;
+        const float* wn = w + (size_t)n * K;
+        for (int c = 0; c < Cin; ++c)
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx)
+                    o[(ky * KW + kx) * Cin + c] = f32_to_bf16_host(sc * wn[(c * KH + ky) * KW + kx]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter registry / upload
+// ------------------------------------------------------------------------------------------------
+static const float* host_param(uni_ctx* c, const std::string& name, size_t n) {
+    auto it = c->host.find(name);
+    if (it == c->host.end() || it->second.data.size() != n) {
+        c->missing.push_back(name);
+        c->zeros.assign(std::max(c->zeros.size(), n), 0.f);
+        return nullptr;
+    }
+    return it->second.data.data();
+}
+
+template <class T>
+static T* dev_upload(uni_ctx* c, const T* h, size_t n) {
+    T* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) {
+        uni_set_error("hipMalloc of %zu bytes failed", n * sizeof(T));
+        c->failed = true;
+        return nullptr;
+    }
+    c->dev_allocs.push_back(d);
+    if (h) {
+        if (hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) c->failed = true;
+    } else {
+        if (hipMemset(d, 0, n * sizeof(T)) != hipSuccess) c->failed = true;
+    }
+    return d;
+}
+
+static float* up_vec(uni_ctx* c, const std::string& name, size_t n) { return dev_upload<float>(c, host_param(c, name, n), n); }
+
+static PAffine up_affine(uni_ctx* c, const std::string& prefix, int C) {
+    PAffine a;
+    a.g = up_vec(c, prefix + "weight", C);
+    a.b = up_vec(c, prefix + "bias", C);
+    return a;
+}
+
+struct ConvSrc { std::string w, b; int N; const float* row_scale = nullptr; };
+
+// one or several (row-concatenated) OIHW convs sharing (Cin,KH,KW) -> packed bf16 + fp32 bias
+static PConv pack_convs(uni_ctx* c, const std::vector<ConvSrc>& srcs, int Cin, int KH, int KW) {
+    PConv p;
+    p.Cin = Cin; p.KH = KH; p.KW = KW;
+    p.K = Cin * KH * KW;
+    p.Kpad = cdiv(p.K, 64) * 64;
+    int N = 0;
+    bool any_bias = false;
+    for (auto& s : srcs) { N += s.N; any_bias |= !s.b.empty(); }
+    p.N = N;
+    const int Npad = cdiv(N, 128) * 128;
+    std::vector<uint16_t> packed((size_t)Npad * p.Kpad, 0);
+    std::vector<float> bias(N, 0.f);
+    int n0 = 0;
+    for (auto& s : srcs) {
+        const float* w = host_param(c, s.w, (size_t)s.N * p.K);
+        if (w) {
+            std::vector<uint16_t> tmp((size_t)cdiv(s.N, 1) * p.Kpad);
+            pack_weight_host(w, s.N, Cin, KH, KW, s.row_scale, tmp.data(), s.N, p.Kpad);
+            memcpy(packed.data() + (size_t)n0 * p.Kpad, tmp.data(), tmp.size() * sizeof(uint16_t));
+        }
+        if (!s.b.empty()) {
+            const float* b = host_param(c, s.b, s.N);
+            if (b)
+                for (int i = 0; i < s.N; ++i) bias[n0 + i] = b[i] * (s.row_scale ? s.row_scale[i] : 1.f);
+        }
+        n0 += s.N;
+    }
+    p.W = reinterpret_cast<bf16*>(dev_upload<uint16_t>(c, packed.data(), packed.size()));
+    p.bias = any_bias ? dev_upload<float>(c, bias.data(), N) : nullptr;
+    return p;
+}
+static PConv pack_conv(uni_ctx* c, const std::string& w, const std::string& b, int N, int Cin, int KH = 1, int KW = 1,
+                       const float* row_scale = nullptr) {
+    return pack_convs(c, {ConvSrc{w, b, N, row_scale}}, Cin, KH, KW);
+}
+
+static PBlock pack_block(uni_ctx* c, const std::string& p, int C) {
+    PBlock b;
+    b.C = C;
+    // depthwise (C,1,7,7) -> [49][C]
+    const float* dw = host_param(c, p + "dwconv.weight", (size_t)C * 49);
+    std::vector<float> t((size_t)49 * C, 0.f);
+    if (dw)
+        for (int ch = 0; ch < C; ++ch)
+            for (int k = 0; k < 49; ++k) t[(size_t)k * C + ch] = dw[(size_t)ch * 49 + k];
+    b.dw_w = dev_upload<float>(c, t.data(), t.size());
+    b.dw_b = up_vec(c, p + "dwconv.bias", C);
+    b.ln = up_affine(c, p + "norm.", C);
+    b.pw1 = pack_conv(c, p + "pwconv1.weight", p + "pwconv1.bias", 4 * C, C);
+    const float* gamma = host_param(c, p + "gamma", C);   // layer scale folded into pwconv2 (convnext.py:50-51)
+    b.pw2 = pack_conv(c, p + "pwconv2.weight", p + "pwconv2.bias", C, 4 * C, 1, 1, gamma);
+    return b;
+}
+
+static PBaseConv pack_baseconv(uni_ctx* c, const std::string& p, int cin, int cout, int k, int stride) {
+    PBaseConv b;
+    b.k = k; b.stride = stride;
+    b.conv = pack_conv(c, p + "conv.weight", "", cout, cin, k, k);
+    b.gn = up_affine(c, p + "bn.", cout);
+    return b;
+}
+
+static PAffine concat_affine(uni_ctx* c, const std::vector<std::string>& prefixes, int C) {
+    std::vector<float> g, b;
+    for (auto& p : prefixes) {
+        const float* hg = host_param(c, p + "weight", C);
+        const float* hb = host_param(c, p + "bias", C);
+        for (int i = 0; i < C; ++i) { g.push_back(hg ? hg[i] : 0.f); b.push_back(hb ? hb[i] : 0.f); }
+    }
+    PAffine a;
+    a.g = dev_upload<float>(c, g.data(), g.size());
+    a.b = dev_upload<float>(c, b.data(), b.size());
+    return a;
+}
+
+static PCsp pack_csp(uni_ctx* c, const std::string& p, int cin, int cout) {
+    PCsp s;
+    s.cin = cin; s.cout = cout; s.h = cout / 2;
+    // conv1 | conv2 share their input -> one GEMM with N = 2h (network_blocks.py:180-182)
+    s.c12 = pack_convs(c, {ConvSrc{p + "conv1.conv.weight", "", s.h}, ConvSrc{p + "conv2.conv.weight", "", s.h}}, cin, 1, 1);
+    s.gn12 = concat_affine(c, {p + "conv1.bn.", p + "conv2.bn."}, s.h);
+    for (int i = 0; i < 3; ++i) {
+        s.m1[i] = pack_baseconv(c, p + "m." + std::to_string(i) + ".conv1.", s.h, s.h, 1, 1);
+        s.m2[i] = pack_baseconv(c, p + "m." + std::to_string(i) + ".conv2.", s.h, s.h, 3, 1);
+    }
+    s.c3 = pack_baseconv(c, p + "conv3.", 2 * s.h, cout, 1, 1);
+    return s;
+}
+
+int engine_finalize(uni_ctx* c) {
+    UNI_CHECK_HIP(hipSetDevice(c->device));
+    const auto& cfg = c->cfg;
+    const int* d = cfg.dims;
+    const std::string bb = "backbone.backbone.";
+    // ---- ConvNeXt ----
+    {
+        const float* w = host_param(c, bb + "downsample_layers.0.0.weight", (size_t)d[0] * 48);
+        std::vector<float> t((size_t)48 * d[0], 0.f);
+        if (w)
+            for (int n = 0; n < d[0]; ++n)
+                for (int k = 0; k < 48; ++k) t[(size_t)k * d[0] + n] = w[(size_t)n * 48 + k];
+        c->stem_w = dev_upload<float>(c, t.data(), t.size());
+        c->stem_b = up_vec(c, bb + "downsample_layers.0.0.bias", d[0]);
+        c->stem_ln = up_affine(c, bb + "downsample_layers.0.1.", d[0]);
+    }
+    for (int i = 1; i < 4; ++i) {
+        std::string p = bb + "downsample_layers." + std::to_string(i) + ".";
+        c->ds_ln[i] = up_affine(c, p + "0.", d[i - 1]);
+        c->ds_conv[i] = pack_conv(c, p + "1.weight", p + "1.bias", d[i], d[i - 1], 2, 2);
+    }
+    for (int i = 0; i < 4; ++i) {
+        c->blocks[i].clear();
+        for (int j = 0; j < cfg.depths[i]; ++j)
+            c->blocks[i].push_back(pack_block(c, bb + "stages." + std::to_string(i) + "." + std::to_string(j) + ".", d[i]));
+    }
+    for (int i = 1; i < 4; ++i) c->out_norm[i] = up_affine(c, bb + "norm" + std::to_string(i) + ".", d[i]);
+    // ---- PAFPN ----
+    const int c0 = d[1], c1 = d[2], c2 = d[3];
+    c->lateral0 = pack_baseconv(c, "backbone.lateral_conv0.", c2, c1, 1, 1);
+    c->c3p4 = pack_csp(c, "backbone.C3_p4.", 2 * c1, c1);
+    c->reduce1 = pack_baseconv(c, "backbone.reduce_conv1.", c1, c0, 1, 1);
+    c->c3p3 = pack_csp(c, "backbone.C3_p3.", 2 * c0, c0);
+    c->bu2 = pack_baseconv(c, "backbone.bu_conv2.", c0, c0, 3, 2);
+    c->c3n3 = pack_csp(c, "backbone.C3_n3.", 2 * c0, c1);
+    c->bu1 = pack_baseconv(c, "backbone.bu_conv1.", c1, c1, 3, 2);
+    c->c3n4 = pack_csp(c, "backbone.C3_n4.", 2 * c1, c2);
+    // ---- head ----
+    const int ch[3] = {c0, c1, c2};
+    for (int k = 0; k < 3; ++k) {
+        const std::string ks = std::to_string(k);
+        c->stems[k] = pack_baseconv(c, "head.stems." + ks + ".", ch[k], 256, 1, 1);
+        c->beta[k] = up_vec(c, "head.beta_" + ks, 256);
+        c->att[k].clear();
+        for (int n = 0; n < cfg.n_layer_att; ++n)
+            c->att[k].push_back(pack_block(c, "head.att_layers." + ks + "." + std::to_string(n) + ".", 256));
+        c->tower0[k] = pack_convs(c, {ConvSrc{"head.cls_convs." + ks + ".0.conv.weight", "", 256},
+                                      ConvSrc{"head.reg_convs." + ks + ".0.conv.weight", "", 256}}, 256, 3, 3);
+        c->tower0_gn[k] = concat_affine(c, {"head.cls_convs." + ks + ".0.bn.", "head.reg_convs." + ks + ".0.bn."}, 256);
+        for (int i = 1; i < 4; ++i) {
+            c->cls_convs[k][i] = pack_baseconv(c, "head.cls_convs." + ks + "." + std::to_string(i) + ".", 256, 256, 3, 1);
+            c->reg_convs[k][i] = pack_baseconv(c, "head.reg_convs." + ks + "." + std::to_string(i) + ".", 256, 256, 3, 1);
+        }
+        c->cls_pred[k] = pack_conv(c, "head.cls_preds." + ks + ".weight", "head.cls_preds." + ks + ".bias", cfg.num_classes, 256);
+        c->cls_pred_sot[k] = pack_conv(c, "head.cls_preds_sot." + ks + ".weight", "head.cls_preds_sot." + ks + ".bias", 1, 256);
+        c->regobj[k] = pack_convs(c, {ConvSrc{"head.reg_preds." + ks + ".weight", "head.reg_preds." + ks + ".bias", 4},
+                                      ConvSrc{"head.obj_preds." + ks + ".weight", "head.obj_preds." + ks + ".bias", 1}}, 256, 1, 1);
+        c->regobj_sot[k] = pack_convs(c, {ConvSrc{"head.reg_preds_sot." + ks + ".weight", "head.reg_preds_sot." + ks + ".bias", 4},
+                                          ConvSrc{"head.obj_preds_sot." + ks + ".weight", "head.obj_preds_sot." + ks + ".bias", 1}}, 256, 1, 1);
+        if (cfg.mask)
+            c->controllers[k] = pack_conv(c, "head.controllers." + ks + ".weight", "head.controllers." + ks + ".bias", 169, 256, 3, 3);
+    }
+    if (cfg.mask) {
+        const std::string mb = "head.mask_branch.";
+        for (int k = 0; k < 3; ++k) {
+            c->refine[k] = pack_conv(c, mb + "refine." + std::to_string(k) + ".0.weight", "", 128, ch[k], 3, 3);
+            c->refine_gn[k] = up_affine(c, mb + "refine." + std::to_string(k) + ".1.", 128);
+        }
+        for (int i = 0; i < 4; ++i) {
+            c->mtower[i] = pack_conv(c, mb + "tower." + std::to_string(i) + ".0.weight", "", 128, 128, 3, 3);
+            c->mtower_gn[i] = up_affine(c, mb + "tower." + std::to_string(i) + ".1.", 128);
+        }
+        c->mtower_out = pack_conv(c, mb + "tower.4.weight", mb + "tower.4.bias", 8, 128);
+        c->upm0 = pack_conv(c, mb + "up_mask_layer.0.weight", mb + "up_mask_layer.0.bias", 128, 128, 3, 3);
+        c->upm1 = pack_conv(c, mb + "up_mask_layer.2.weight", mb + "up_mask_layer.2.bias", 9 * cfg.up_rate * cfg.up_rate, 128);
+    }
+    // ---- interaction / embedding ----
+    c->bott = pack_conv(c, "bottleneck.0.weight", "bottleneck.0.bias", 256, c1);
+    c->bott_gn = up_affine(c, "bottleneck.1.", 256);
+    const std::string e = "transformer.encoder.layers.0.";
+    c->value_proj = pack_conv(c, e + "self_attn.value_proj.weight", e + "self_attn.value_proj.bias", 256, 256);
+    c->offaw = pack_convs(c, {ConvSrc{e + "self_attn.sampling_offsets.weight", e + "self_attn.sampling_offsets.bias", 128},
+                              ConvSrc{e + "self_attn.attention_weights.weight", e + "self_attn.attention_weights.bias", 64}}, 256, 1, 1);
+    c->output_proj = pack_conv(c, e + "self_attn.output_proj.weight", e + "self_attn.output_proj.bias", 256, 256);
+    c->lin1 = pack_conv(c, e + "linear1.weight", e + "linear1.bias", 1024, 256);
+    c->lin2 = pack_conv(c, e + "linear2.weight", e + "linear2.bias", 256, 1024);
+    c->norm1 = up_affine(c, e + "norm1.", 256);
+    c->norm2 = up_affine(c, e + "norm2.", 256);
+    c->level_embed = up_vec(c, "transformer.level_embed", 512);
+    c->up1 = pack_conv(c, "upsample_layer.1.weight", "upsample_layer.1.bias", 256, 64, 3, 3);
+    c->up3 = pack_conv(c, "upsample_layer.3.weight", "upsample_layer.3.bias", cfg.embed_dim, 256, 3, 3);
+    c->pos_row = up_vec(c, "pos_emb.row_embed.weight", 40 * 128);
+    c->pos_col = up_vec(c, "pos_emb.col_embed.weight", 40 * 128);
+    // GroupNorm statistics arena (zeroed at the start of every stage call)
+    UNI_CHECK_HIP(hipMalloc(&c->stats, UNI_STATS_SLOTS * 64 * sizeof(double)));
+    c->dev_allocs.push_back(c->stats);
+    UNI_REQUIRE(!c->failed, "finalize: device upload failed");
+    c->host.clear();      // host copies are no longer needed
+    c->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+int engine_reserve(uni_ctx* c, int H, int W) {
+    const size_t need = (size_t)H * W * 3200 + ((size_t)96 << 20);
+    if (need <= c->ws_cap) return 0;
+    UNI_CHECK_HIP(hipSetDevice(c->device));
+    UNI_CHECK_HIP(hipDeviceSynchronize());    // growing is rare; never happens inside a timed loop after warm-up
+    if (c->ws) UNI_CHECK_HIP(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_cap = 0;
+    UNI_CHECK_HIP(hipMalloc(&c->ws, need));
+    c->ws_cap = need;
+    return 0;
+}
+
+template <class T>
+static T* wsalloc(uni_ctx* c, size_t n) {
+    size_t off = (c->ws_off + 255) & ~(size_t)255;
+    size_t bytes = n * sizeof(T);
+    if (off + bytes > c->ws_cap) {
+        c->ws_overflow = true;
+        uni_set_error("workspace overflow: need %zu more bytes (cap %zu)", off + bytes - c->ws_cap, c->ws_cap);
+        return reinterpret_cast<T*>(c->ws);   // keep pointers valid; the stage returns an error before launching more
+    }
+    c->ws_off = off + bytes;
+    return reinterpret_cast<T*>(c->ws + off);
+}
+
+static int stage_begin(uni_ctx* c, int H, int W, hipStream_t s) {
+    UNI_REQUIRE(c && c->finalized, "context not finalized");
+    UNI_CHECK_HIP(hipSetDevice(c->device));
+    int rc = engine_reserve(c, H, W);
+    if (rc) return rc;
+    c->ws_off = 0;
+    c->ws_overflow = false;
+    c->stats_slot = 0;
+    UNI_CHECK_HIP(hipMemsetAsync(c->stats, 0, UNI_STATS_SLOTS * 64 * sizeof(double), s));
+    return 0;
+}
+static double* next_stats(uni_ctx* c) {
+    if (c->stats_slot >= UNI_STATS_SLOTS) { c->ws_overflow = true; uni_set_error("GN stats arena exhausted"); return c->stats; }
+    return c->stats + (size_t)(c->stats_slot++) * 64;
+}
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; if (c->ws_overflow) return -3; } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// building blocks
+// ------------------------------------------------------------------------------------------------
+struct Out {
+    float* F = nullptr; int ldf = 0;
+    bf16* B = nullptr; int ldb = 0;
+    bf16* Up = nullptr; int ldu = 0;
+    const float* prior = nullptr; const float* pbeta = nullptr;
+};
+
+static GemmArgs conv_args(const PConv& p, const bf16* A, int lda, int Hin, int Win, int stride, int pad) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = p.W;
+    const int Hout = (Hin + 2 * pad - p.KH) / stride + 1, Wout = (Win + 2 * pad - p.KW) / stride + 1;
+    g.M = Hout * Wout; g.N = p.N; g.K = p.K; g.Kpad = p.Kpad;
+    g.Hin = Hin; g.Win = Win; g.Cin = p.Cin; g.KH = p.KH; g.KW = p.KW; g.stride = stride; g.pad = pad; g.Wout = Wout;
+    g.bias = p.bias;
+    return g;
+}
+
+// conv (no act) -> GroupNorm(G) -> act, written to `o`
+static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, float eps, int act, const bf16* A, int lda,
+                       int Hin, int Win, int stride, const Out& o, hipStream_t s) {
+    const size_t mark = c->ws_off;
+    GemmArgs g = conv_args(conv, A, lda, Hin, Win, stride, (conv.KH - 1) / 2);
+    float* raw = wsalloc<float>(c, (size_t)g.M * g.N);
+    double* st = next_stats(c);
+    g.outF = raw; g.ldf = g.N; g.stats = st; g.cpg = g.N / G;
+    RUN(launch_gemm(g, s));
+    GnApplyArgs a;
+    a.x = raw; a.ldx = g.N; a.stats = st; a.gamma = gn.g; a.beta = gn.b; a.eps = eps;
+    a.M = g.M; a.C = g.N; a.G = G; a.act = act;
+    a.prior = o.prior; a.prior_beta = o.pbeta;
+    a.outF = o.F; a.ldf = o.ldf; a.outB = o.B; a.ldb = o.ldb; a.outUp = o.Up; a.ldu = o.ldu;
+    a.W = (Win + 2 * ((conv.KW - 1) / 2) - conv.KW) / stride + 1;
+    RUN(launch_gn_apply(a, s));
+    c->ws_off = mark;     // raw is dead once gn_apply is enqueued (single in-order stream)
+    return 0;
+}
+static int run_baseconv(uni_ctx* c, const PBaseConv& b, const bf16* A, int lda, int Hin, int Win, const Out& o, hipStream_t s) {
+    return run_conv_gn(c, b.conv, b.gn, 16, 1e-3f, ACT_SILU, A, lda, Hin, Win, b.stride, o, s);
+}
+
+// ConvNeXt block on the fp32 residual stream x [H*W][C] (in place); t/hid are caller-provided scratch
+static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, bf16* t, bf16* hid, bf16* outB, hipStream_t s) {
+    const int C = b.C, M = H * W;
+    DwLnArgs d;
+    d.x = x; d.w = b.dw_w; d.bias = b.dw_b; d.gamma = b.ln.g; d.beta = b.ln.b; d.eps = 1e-6f;
+    d.H = H; d.W = W; d.C = C; d.out = t;
+    RUN(launch_dwconv7_ln(d, s));
+    GemmArgs g1 = conv_args(b.pw1, t, C, M, 1, 1, 0);
+    g1.act = ACT_GELU; g1.outB = hid; g1.ldb = 4 * C;
+    RUN(launch_gemm(g1, s));
+    GemmArgs g2 = conv_args(b.pw2, hid, 4 * C, M, 1, 1, 0);
+    g2.res = x; g2.ldr = C; g2.outF = x; g2.ldf = C; g2.outB = outB; g2.ldb = C;
+    RUN(launch_gemm(g2, s));
+    return 0;
+}
+
+// CSP layer: cat buffer `in` [M][cin] bf16 -> `o`
+static int run_csp(uni_ctx* c, const PCsp& p, const bf16* in, int H, int W, const Out& o, hipStream_t s) {
+    const int M = H * W, h = p.h;
+    const size_t mark = c->ws_off;
+    bf16* cat = wsalloc<bf16>(c, (size_t)M * 2 * h);     // [x_1 | x_2]
+    bf16* t1 = wsalloc<bf16>(c, (size_t)M * h);
+    bf16* t2 = wsalloc<bf16>(c, (size_t)M * h);
+    Out o12; o12.B = cat; o12.ldb = 2 * h;
+    RUN(run_conv_gn(c, p.c12, p.gn12, 32, 1e-3f, ACT_SILU, in, p.cin, H, W, 1, o12, s));
+    const bf16* cur = cat; int ld = 2 * h;
+    for (int i = 0; i < 3; ++i) {
+        Out a; a.B = t1; a.ldb = h;
+        RUN(run_baseconv(c, p.m1[i], cur, ld, H, W, a, s));
+        Out b2;
+        if (i == 2) { b2.B = cat; b2.ldb = 2 * h; } else { b2.B = t2; b2.ldb = h; }
+        RUN(run_baseconv(c, p.m2[i], t1, h, H, W, b2, s));
+        cur = t2; ld = h;
+    }
+    RUN(run_baseconv(c, p.c3, cat, 2 * h, H, W, o, s));
+    c->ws_off = mark;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: backbone + PAFPN   (unicorn.py:231-258)
+// ------------------------------------------------------------------------------------------------
+int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
+                        hipStream_t s) {
+    UNI_REQUIRE(H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0, "backbone: H=%d W=%d must be positive multiples of 32", H, W);
+    RUN(stage_begin(c, H, W, s));
+    const int* d = c->cfg.dims;
+    const int c0 = d[1], c1 = d[2], c2 = d[3];
+    const int H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
+    const int M8 = H8 * W8, M16 = H16 * W16, M32 = H32 * W32;
+    // persistent (for this call) PAFPN inputs
+    bf16* cat8 = wsalloc<bf16>(c, (size_t)M8 * 2 * c0);      // [up(fpn_out1) | x2]
+    bf16* cat16a = wsalloc<bf16>(c, (size_t)M16 * 2 * c1);   // [up(fpn_out0) | x1]
+    bf16* cat16b = wsalloc<bf16>(c, (size_t)M16 * 2 * c0);   // [p_out1 | fpn_out1]
+    bf16* cat32 = wsalloc<bf16>(c, (size_t)M32 * 2 * c1);    // [p_out0 | fpn_out0]
+    bf16* x0b = wsalloc<bf16>(c, (size_t)M32 * c2);
+    // ---- ConvNeXt ----
+    {
+        int Hs = H / 4, Ws = W / 4;
+        float* x = wsalloc<float>(c, (size_t)Hs * Ws * d[0]);
+        StemArgs st;
+        st.img = img; st.H = H; st.W = W; st.w = c->stem_w; st.bias = c->stem_b; st.gamma = c->stem_ln.g; st.beta = c->stem_ln.b;
+        st.C = d[0]; st.out = x;
+        RUN(launch_stem(st, s));
+        for (int i = 0; i < 4; ++i) {
+            if (i > 0) {
+                // LN_cf + conv2x2/s2 (convnext.py:80-86)
+                bf16* t = wsalloc<bf16>(c, (size_t)Hs * Ws * d[i - 1]);
+                LnArgs ln;
+                ln.x = x; ln.ldx = d[i - 1]; ln.gamma = c->ds_ln[i].g; ln.beta = c->ds_ln[i].b; ln.eps = 1e-6f;
+                ln.M = Hs * Ws; ln.C = d[i - 1]; ln.outB = t; ln.ldb = d[i - 1];
+                RUN(launch_layernorm(ln, s));
+                float* xn = wsalloc<float>(c, (size_t)(Hs / 2) * (Ws / 2) * d[i]);
+                GemmArgs g = conv_args(c->ds_conv[i], t, d[i - 1], Hs, Ws, 2, 0);
+                g.outF = xn; g.ldf = d[i];
+                RUN(launch_gemm(g, s));
+                x = xn; Hs /= 2; Ws /= 2;
+            }
+            const int M = Hs * Ws, C = d[i];
+            bf16* t = wsalloc<bf16>(c, (size_t)M * C);
+            bf16* hid = wsalloc<bf16>(c, (size_t)M * 4 * C);
+            for (auto& b : c->blocks[i]) RUN(run_block(c, b, x, Hs, Ws, t, hid, nullptr, s));
+            if (i >= 1) {
+                LnArgs ln;
+                ln.x = x; ln.ldx = C; ln.gamma = c->out_norm[i].g; ln.beta = c->out_norm[i].b; ln.eps = 1e-6f;
+                ln.M = M; ln.C = C;
+                if (i == 1) { ln.outB = cat8 + c0; ln.ldb = 2 * c0; }
+                else if (i == 2) { ln.outB = cat16a + c1; ln.ldb = 2 * c1; ln.outF = feat16; ln.ldf = c1; }
+                else { ln.outB = x0b; ln.ldb = c2; }
+                RUN(launch_layernorm(ln, s));
+            }
+        }
+    }
+    // ---- PAFPN (yolo_pafpn_new.py:132-161) ----
+    {
+        Out o;  // fpn_out0 -> cat32[:, c1:] and 2x-upsampled into cat16a[:, :c1]
+        o.B = cat32 + c1; o.ldb = 2 * c1; o.Up = cat16a; o.ldu = 2 * c1;
+        RUN(run_baseconv(c, c->lateral0, x0b, c2, H32, W32, o, s));
+    }
+    bf16* f_out0 = wsalloc<bf16>(c, (size_t)M16 * c1);
+    { Out o; o.B = f_out0; o.ldb = c1; RUN(run_csp(c, c->c3p4, cat16a, H16, W16, o, s)); }
+    {
+        Out o;  // fpn_out1 -> cat16b[:, c0:] and upsampled into cat8[:, :c0]
+        o.B = cat16b + c0; o.ldb = 2 * c0; o.Up = cat8; o.ldu = 2 * c0;
+        RUN(run_baseconv(c, c->reduce1, f_out0, c1, H16, W16, o, s));
+    }
+    bf16* pan2b = wsalloc<bf16>(c, (size_t)M8 * c0);
+    { Out o; o.F = fpn0; o.ldf = c0; o.B = pan2b; o.ldb = c0; RUN(run_csp(c, c->c3p3, cat8, H8, W8, o, s)); }
+    { Out o; o.B = cat16b; o.ldb = 2 * c0; RUN(run_baseconv(c, c->bu2, pan2b, c0, H8, W8, o, s)); }
+    bf16* pan1b = wsalloc<bf16>(c, (size_t)M16 * c1);
+    { Out o; o.F = fpn1; o.ldf = c1; o.B = pan1b; o.ldb = c1; RUN(run_csp(c, c->c3n3, cat16b, H16, W16, o, s)); }
+    { Out o; o.B = cat32; o.ldb = 2 * c1; RUN(run_baseconv(c, c->bu1, pan1b, c1, H16, W16, o, s)); }
+    { Out o; o.F = fpn2; o.ldf = c2; RUN(run_csp(c, c->c3n4, cat32, H32, W32, o, s)); }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: deformable interaction   (unicorn.py:260-276, deformable_transformer.py:58-131)
+// ------------------------------------------------------------------------------------------------
+int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,
+                       int h, int w, float* out_ref, float* out_cur, hipStream_t s) {
+    RUN(stage_begin(c, h * 16, w * 16, s));
+    const int hw = h * w, L = 2 * hw, C2 = c->cfg.dims[2];
+    bf16* fb = wsalloc<bf16>(c, (size_t)L * C2);
+    RUN(launch_cast_bf16(feat_ref, C2, fb, C2, hw, C2, s));
+    RUN(launch_cast_bf16(feat_cur, C2, fb + (size_t)hw * C2, C2, hw, C2, s));
+    float* src = wsalloc<float>(c, (size_t)L * 256);
+    bf16* srcb = wsalloc<bf16>(c, (size_t)L * 256);
+    for (int l = 0; l < 2; ++l) {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5), per frame
+        Out o; o.F = src + (size_t)l * hw * 256; o.ldf = 256; o.B = srcb + (size_t)l * hw * 256; o.ldb = 256;
+        RUN(run_conv_gn(c, c->bott, c->bott_gn, 32, 1e-5f, ACT_NONE, fb + (size_t)l * hw * C2, C2, hw, 1, 1, o, s));
+    }
+    bf16* qb = wsalloc<bf16>(c, (size_t)L * 256);
+    RUN(launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s));
+    float* value = wsalloc<float>(c, (size_t)L * 256);
+    { GemmArgs g = conv_args(c->value_proj, srcb, 256, L, 1, 1, 0); g.outF = value; g.ldf = 256; RUN(launch_gemm(g, s)); }
+    float* offaw = wsalloc<float>(c, (size_t)L * 192);
+    { GemmArgs g = conv_args(c->offaw, qb, 256, L, 1, 1, 0); g.outF = offaw; g.ldf = 192; RUN(launch_gemm(g, s)); }
+    bf16* attn = wsalloc<bf16>(c, (size_t)L * 256);
+    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; RUN(launch_msda_fused(m, s)); }
+    float* y = wsalloc<float>(c, (size_t)L * 256);
+    { GemmArgs g = conv_args(c->output_proj, attn, 256, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(launch_gemm(g, s)); }
+    {   // src = norm1(src + attn)
+        LnArgs ln; ln.x = y; ln.ldx = 256; ln.gamma = c->norm1.g; ln.beta = c->norm1.b; ln.eps = 1e-5f; ln.M = L; ln.C = 256;
+        ln.outF = src; ln.ldf = 256; ln.outB = srcb; ln.ldb = 256;
+        RUN(launch_layernorm(ln, s));
+    }
+    bf16* hid = wsalloc<bf16>(c, (size_t)L * 1024);
+    { GemmArgs g = conv_args(c->lin1, srcb, 256, L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->lin2, hid, 1024, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(launch_gemm(g, s)); }
+    for (int l = 0; l < 2; ++l) {
+        LnArgs ln; ln.x = y + (size_t)l * hw * 256; ln.ldx = 256; ln.gamma = c->norm2.g; ln.beta = c->norm2.b; ln.eps = 1e-5f;
+        ln.M = hw; ln.C = 256; ln.outF = l ? out_cur : out_ref; ln.ldf = 256;
+        RUN(launch_layernorm(ln, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: embedding head   (unicorn.py:41-44,311-313)
+// ------------------------------------------------------------------------------------------------
+int engine_upsample(uni_ctx* c, const float* feat, int h, int w, float* embed, hipStream_t s) {
+    RUN(stage_begin(c, h * 16, w * 16, s));
+    const int H = 2 * h, W = 2 * w, M = H * W;
+    bf16* ps = wsalloc<bf16>(c, (size_t)M * 64);
+    RUN(launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s));
+    bf16* mid = wsalloc<bf16>(c, (size_t)M * 256);
+    { GemmArgs g = conv_args(c->up1, ps, 64, H, W, 1, 1); g.act = ACT_RELU; g.outB = mid; g.ldb = 256; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->up3, mid, 256, H, W, 1, 1); g.outF = embed; g.ldf = c->cfg.embed_dim; RUN(launch_gemm(g, s)); }
+    return 0;
+}
+
+int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s) {
+    UNI_REQUIRE(c && c->finalized, "context not finalized");
+    return launch_pos_embed(c->pos_row, c->pos_col, 40, 128, out, h, w, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: unified head (+ mask branch / controllers)   (unicorn_head.py:249-336, unicorn_head_mask.py:280-372)
+// ------------------------------------------------------------------------------------------------
+int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
+                const float* prior16, const float* prior32, int H, int W, int mode, float* out, float* dyn_params,
+                float* mask_feats, float* up_masks, hipStream_t s) {
+    UNI_REQUIRE(mode == 0 || mode == 1, "head: mode has to be 0 ('sot') or 1 ('mot')");   // unicorn_head.py:291-292
+    UNI_REQUIRE(H % 32 == 0 && W % 32 == 0, "head: H=%d W=%d", H, W);
+    RUN(stage_begin(c, H, W, s));
+    const auto& cfg = c->cfg;
+    if (cfg.mask) UNI_REQUIRE(dyn_params && mask_feats && up_masks, "head: mask model needs dyn_params/mask_feats/up_masks");
+    const int ch[3] = {cfg.dims[1], cfg.dims[2], cfg.dims[3]};
+    const int Hk[3] = {H / 8, H / 16, H / 32}, Wk[3] = {W / 8, W / 16, W / 32};
+    const float* fpn[3] = {fpn0, fpn1, fpn2};
+    const float* prior[3] = {prior8, prior16, prior32};
+    const int ncls = mode == 0 ? 1 : cfg.num_classes, nch = 5 + ncls;
+    bf16* fb[3];
+    for (int k = 0; k < 3; ++k) {
+        fb[k] = wsalloc<bf16>(c, (size_t)Hk[k] * Wk[k] * ch[k]);
+        RUN(launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s));
+    }
+    int row0 = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int M = Hk[k] * Wk[k];
+        const size_t mark = c->ws_off;
+        float* x = wsalloc<float>(c, (size_t)M * 256);
+        { Out o; o.F = x; o.ldf = 256; o.prior = prior[k]; o.pbeta = c->beta[k]; RUN(run_baseconv(c, c->stems[k], fb[k], ch[k], Hk[k], Wk[k], o, s)); }
+        bf16* t = wsalloc<bf16>(c, (size_t)M * 256);
+        bf16* hid = wsalloc<bf16>(c, (size_t)M * 1024);
+        bf16* xb = wsalloc<bf16>(c, (size_t)M * 256);
+        const int nb = (int)c->att[k].size();
+        if (nb == 0) RUN(launch_cast_bf16(x, 256, xb, 256, M, 256, s));
+        for (int n = 0; n < nb; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nb - 1 ? xb : nullptr, s));
+        bf16* tw = wsalloc<bf16>(c, (size_t)M * 512);      // [cls | reg] after the first (merged) tower conv
+        { Out o; o.B = tw; o.ldb = 512; RUN(run_conv_gn(c, c->tower0[k], c->tower0_gn[k], 32, 1e-3f, ACT_SILU, xb, 256, Hk[k], Wk[k], 1, o, s)); }
+        bf16* cb[2] = {wsalloc<bf16>(c, (size_t)M * 256), wsalloc<bf16>(c, (size_t)M * 256)};
+        bf16* rb[2] = {wsalloc<bf16>(c, (size_t)M * 256), wsalloc<bf16>(c, (size_t)M * 256)};
+        const bf16* cls = tw; const bf16* reg = tw + 256; int ldc = 512;
+        for (int i = 1; i < 4; ++i) {
+            { Out o; o.B = cb[i & 1]; o.ldb = 256; RUN(run_baseconv(c, c->cls_convs[k][i], cls, ldc, Hk[k], Wk[k], o, s)); }
+            { Out o; o.B = rb[i & 1]; o.ldb = 256; RUN(run_baseconv(c, c->reg_convs[k][i], reg, ldc, Hk[k], Wk[k], o, s)); }
+            cls = cb[i & 1]; reg = rb[i & 1]; ldc = 256;
+        }
+        float* ok = out + (size_t)row0 * nch;
+        {   // [reg(4) | sigmoid(obj)]  (unicorn_head.py:295-304,332-334)
+            GemmArgs g = conv_args(mode == 0 ? c->regobj_sot[k] : c->regobj[k], reg, ldc, M, 1, 1, 0);
+            g.act = ACT_SIGMOID; g.act_col0 = 4; g.outF = ok; g.ldf = nch;
+            RUN(launch_gemm(g, s));
+        }
+        {   // sigmoid(cls)
+            GemmArgs g = conv_args(mode == 0 ? c->cls_pred_sot[k] : c->cls_pred[k], cls, ldc, M, 1, 1, 0);
+            g.act = ACT_SIGMOID; g.outF = ok + 5; g.ldf = nch;
+            RUN(launch_gemm(g, s));
+        }
+        if (cfg.mask) {   // controllers on reg_feat (ctrl_loc == "reg", unicorn_head_mask.py:333-340)
+            GemmArgs g = conv_args(c->controllers[k], reg, ldc, Hk[k], Wk[k], 1, 1);
+            g.outF = dyn_params + (size_t)row0 * 169; g.ldf = 169;
+            RUN(launch_gemm(g, s));
+        }
+        row0 += M;
+        c->ws_off = mark;
+    }
+    RUN(launch_decode(out, out, Hk[0] * Wk[0], Wk[0], Hk[1] * Wk[1], Wk[1], Hk[2] * Wk[2], Wk[2], nch, s));
+    if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162
+        const int M8 = Hk[0] * Wk[0];
+        float* xm = wsalloc<float>(c, (size_t)M8 * 128);
+        for (int k = 0; k < 3; ++k) {
+            const int M = Hk[k] * Wk[k];
+            float* r = k == 0 ? xm : wsalloc<float>(c, (size_t)M * 128);
+            Out o; o.F = r; o.ldf = 128;
+            RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
+            if (k > 0) RUN(launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s));
+        }
+        bf16* xmb = wsalloc<bf16>(c, (size_t)M8 * 128);
+        RUN(launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s));
+        bf16* tb[2] = {wsalloc<bf16>(c, (size_t)M8 * 128), wsalloc<bf16>(c, (size_t)M8 * 128)};
+        const bf16* cur = xmb;
+        for (int i = 0; i < 4; ++i) {
+            Out o; o.B = tb[i & 1]; o.ldb = 128;
+            RUN(run_conv_gn(c, c->mtower[i], c->mtower_gn[i], 16, 1e-3f, ACT_RELU, cur, 128, Hk[0], Wk[0], 1, o, s));
+            cur = tb[i & 1];
+        }
+        { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(launch_gemm(g, s)); }
+        bf16* u = tb[0] == cur ? tb[1] : tb[0];
+        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(launch_gemm(g, s)); }
+        { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(launch_gemm(g, s)); }
+    }
+    return 0;
+}
+
+void engine_destroy(uni_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void* p : c->dev_allocs) hipFree(p);
+    if (c->ws) hipFree(c->ws);
+    delete c;
+}

@@ -1,0 +1,112 @@
+// Internal launcher interface between the HIP kernels (*.hip) and the engine / C-ABI (engine.hip, api.hip).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- gemm.hip
+struct GemmArgs {
+    const bf16* A = nullptr; int lda = 0;     // NHWC bf16 activations, lda = elements per pixel row
+    const bf16* W = nullptr;                  // packed [Npad][Kpad] bf16
+    int M = 0, N = 0, K = 0, Kpad = 0;
+    // conv geometry (1x1/s1/p0 => plain GEMM)
+    int Hin = 0, Win = 0, Cin = 0, KH = 1, KW = 1, stride = 1, pad = 0, Wout = 0;
+    // epilogue
+    const float* bias = nullptr;              // [N]
+    int act = ACT_NONE; int act_col0 = 0;     // activation on columns >= act_col0
+    const float* res = nullptr; int ldr = 0;  // fp32 residual added after the activation
+    float* outF = nullptr; int ldf = 0;
+    bf16* outB = nullptr; int ldb = 0;
+    double* stats = nullptr; int cpg = 0;     // GroupNorm group sums [G][2] of (acc+bias), cpg = channels/group
+    int force_cfg = 0;                        // 0 = heuristic, else 22 / 12 / 21 / 11
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- norm.hip
+// Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.
+struct LnArgs {
+    const float* x = nullptr; int ldx = 0;
+    const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-6f;
+    int M = 0, C = 0;
+    float* outF = nullptr; int ldf = 0;
+    bf16* outB = nullptr; int ldb = 0;
+    // optional PixelShuffle(2) scatter of the bf16 output (unicorn.py:41): row=(y,x) of an (h,w) map,
+    // channel c -> pixel (2y+dy, 2x+dx), channel c/4 of a (2h,2w,C/4) map
+    int ps_h = 0, ps_w = 0;
+};
+int launch_layernorm(const LnArgs& a, hipStream_t s);
+
+// GroupNorm apply from group sums + activation (+ prior fusion), fp32 [M][C] raw -> bf16 / fp32 (+2x nearest copy)
+struct GnApplyArgs {
+    const float* x = nullptr; int ldx = 0;
+    const double* stats = nullptr;            // [G][2] sum, sumsq
+    const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-3f;
+    int M = 0, C = 0, G = 16, act = ACT_SILU;
+    const float* prior = nullptr; const float* prior_beta = nullptr;   // y += prior[m] * prior_beta[c]
+    float* outF = nullptr; int ldf = 0;
+    bf16* outB = nullptr; int ldb = 0;
+    bf16* outUp = nullptr; int ldu = 0; int W = 0;   // 2x nearest upsampled copy into a (2H,2W) map
+};
+int launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
+
+// depthwise 7x7 (+bias) + LayerNorm(C): fp32 NHWC -> bf16 [M][C]
+struct DwLnArgs {
+    const float* x = nullptr;                 // [H][W][C]
+    const float* w = nullptr;                 // [49][C]
+    const float* bias = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    float eps = 1e-6f;
+    int H = 0, W = 0, C = 0;
+    bf16* out = nullptr;
+};
+int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s);
+
+// stem: conv4x4/s4 (3->C) + bias + LN_cf: NCHW fp32 image -> fp32 NHWC
+struct StemArgs {
+    const float* img = nullptr; int H = 0, W = 0;   // (3,H,W)
+    const float* w = nullptr;                       // [48][C]  (k = c*16 + ky*4 + kx)
+    const float* bias = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+    int C = 0; float* out = nullptr;                // [H/4][W/4][C]
+};
+int launch_stem(const StemArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- msda.hip
+// reference-compatible op (ops/src/vision.cpp:13-16): value [N,S,M,D], loc [N,Lq,M,L,P,2], attn [N,Lq,M,L,P]
+int launch_msda(const float* value, const int64_t* shapes_host, const int64_t* lsi_host, const float* loc,
+                const float* attn, float* out, int N, int S, int M, int D, int Lq, int L, int P, hipStream_t s);
+// fused engine variant: raw offsets / attention logits -> softmax, loc = ref + off/(W,H), sample, bf16 out
+struct MsdaFusedArgs {
+    const float* value = nullptr;             // [2*hw][256] fp32
+    const float* offaw = nullptr; int ldo = 0;   // [Lq][192]: 128 offsets (m,l,p,xy) | 64 logits (m,l,p)
+    int h = 0, w = 0;                         // both levels (h,w); Lq = 2*h*w
+    bf16* out = nullptr;                      // [Lq][256]
+};
+int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- corr.hip
+// out[k][q] = sum_r V[k][r] softmax_r(<Eref[r], Ecur[q]>);  Eref [R][D], Ecur [Q][D] fp32 row-major, V [K][R]
+int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,
+                int precision, void* workspace, size_t ws_bytes, hipStream_t s);
+size_t corr_workspace_bytes(int R, int Q, int K);
+
+// ---------------------------------------------------------------- misc.hip
+int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s);
+int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s);
+int launch_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, hipStream_t s);
+int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s);
+int launch_add_aligned_bilinear(const float* src, int h, int w, int C, int factor, float* dst, hipStream_t s);
+int launch_pos_embed(const float* row, const float* col, int sz, int nf, float* out, int h, int w, hipStream_t s);
+int launch_sample_embed(const float* emb, int H, int W, int C, const float* boxes, int ldbox, int n, float stride,
+                        float* out, hipStream_t s);
+struct CondInstArgs {
+    const float* mask_feats = nullptr;        // [H][W][8] fp32
+    const float* up_masks = nullptr;          // [H][W][9*r*r] fp32
+    const float* params = nullptr; int ldp = 0;   // [n][169]
+    const float* inst_loc = nullptr;          // [n][2]
+    const int* inst_lvl = nullptr;            // [n]
+    int n = 0, H = 0, W = 0, r = 4, d_rate = 2;
+    float* logits_ws = nullptr;               // [n][H][W] workspace
+    float* coarse_ws = nullptr;               // [n][rH][rW] workspace (sigmoid scores at 1/d_rate res)
+    float* out = nullptr;                     // [n][d_rate*r*H][d_rate*r*W]
+};
+int launch_condinst(const CondInstArgs& a, hipStream_t s);
+int launch_label_map_s8(const float* box_xyxy, float* out, int H, int W, hipStream_t s);
+int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,
+                        int C, hipStream_t s);

@@ -1,0 +1,108 @@
+// K3: multi-scale deformable attention forward (replaces the reference's only hand-written CUDA op,
+// unicorn/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299, bilinear :33-84).
+// One lane per (query, head, channel); the D channels of a head are consecutive lanes so every corner
+// fetch is one contiguous D*4-byte segment of the value map (value is 8 MB at 800x1280 -> L2/MALL
+// resident); sampling locations / weights are wave-broadcast loads.  Gather-latency bound, no LDS needed.
+#include "kernels.h"
+
+struct MsdaShapes { int H[8], W[8], start[8]; };
+
+__device__ __forceinline__ float msda_bilinear(const float* v, int H, int W, int stride, float h, float w) {
+    // ms_deform_im2col_cuda.cuh:33-84: corners outside the map contribute 0
+    const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+    const float lh = h - h0, lw = w - w0, hh = 1.f - lh, hw = 1.f - lw;
+    const int h1 = h0 + 1, w1 = w0 + 1;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    if (h0 >= 0 && w0 >= 0) v1 = v[(size_t)(h0 * W + w0) * stride];
+    if (h0 >= 0 && w1 <= W - 1) v2 = v[(size_t)(h0 * W + w1) * stride];
+    if (h1 <= H - 1 && w0 >= 0) v3 = v[(size_t)(h1 * W + w0) * stride];
+    if (h1 <= H - 1 && w1 <= W - 1) v4 = v[(size_t)(h1 * W + w1) * stride];
+    return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+
+__global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ value, const float* __restrict__ loc,
+                                                   const float* __restrict__ attn, float* __restrict__ out,
+                                                   MsdaShapes shp, int N, int S, int M, int D, int Lq, int L, int P) {
+    const long total = (long)N * Lq * M * D;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int d = idx % D;
+    const int m = (idx / D) % M;
+    const int q = (idx / ((long)D * M)) % Lq;
+    const int n = idx / ((long)D * M * Lq);
+    const float* lp = loc + (((size_t)n * Lq + q) * M + m) * L * P * 2;
+    const float* ap = attn + (((size_t)n * Lq + q) * M + m) * L * P;
+    const int stride = M * D;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int H = shp.H[l], W = shp.W[l];
+        const float* vb = value + ((size_t)n * S + shp.start[l]) * stride + m * D + d;
+        for (int pt = 0; pt < P; ++pt) {
+            const float x = lp[(l * P + pt) * 2] * W - 0.5f;
+            const float y = lp[(l * P + pt) * 2 + 1] * H - 0.5f;
+            const float wgt = ap[l * P + pt];
+            if (y > -1 && x > -1 && y < H && x < W) acc += wgt * msda_bilinear(vb, H, W, stride, y, x);
+        }
+    }
+    out[idx] = acc;
+}
+
+int launch_msda(const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                float* out, int N, int S, int M, int D, int Lq, int L, int P, hipStream_t s) {
+    UNI_REQUIRE(L >= 1 && L <= 8, "msda: n_levels=%d unsupported (1..8)", L);
+    MsdaShapes shp;
+    long tot = 0;
+    for (int l = 0; l < L; ++l) {
+        shp.H[l] = (int)shapes[2 * l];
+        shp.W[l] = (int)shapes[2 * l + 1];
+        shp.start[l] = (int)lsi[l];
+        tot += shapes[2 * l] * shapes[2 * l + 1];
+    }
+    UNI_REQUIRE(tot == S, "msda: sum(H*W)=%ld != S=%d", tot, S);   // ms_deform_attn.py:94
+    const long total = (long)N * Lq * M * D;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(msda_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, value, loc, attn, out, shp,
+                       N, S, M, D, Lq, L, P);
+    return 0;
+}
+
+// Engine variant for Unicorn's fixed geometry (8 heads x 32 ch, 2 levels = ref / cur frame of identical
+// (h,w), 4 points): fuses ms_deform_attn.py:98-105 (softmax over the 8 logits, loc = ref + off/(W,H)) and
+// deformable_transformer.py:141-153 (reference points) into the sampler; emits bf16 for output_proj.
+__global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs p) {
+    const int hw = p.h * p.w, Lq = 2 * hw;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Lq * 256) return;
+    const int d = idx & 31, m = (idx >> 5) & 7, q = (int)(idx >> 8);
+    const float* row = p.offaw + (size_t)q * p.ldo;
+    const float* off = row + m * 16;
+    const float* lg = row + 128 + m * 8;
+    float w8[8], mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w8[i] = lg[i]; mx = fmaxf(mx, w8[i]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w8[i] = __expf(w8[i] - mx); sum += w8[i]; }
+    const float inv = 1.f / sum;
+    const int pos = q % hw, i0 = pos / p.w, j0 = pos - i0 * p.w;
+    const float refx = (j0 + 0.5f) / p.w, refy = (i0 + 0.5f) / p.h;
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const float* vb = p.value + (size_t)l * hw * 256 + m * 32 + d;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const float lx = refx + off[(l * 4 + pt) * 2] / p.w;
+            const float ly = refy + off[(l * 4 + pt) * 2 + 1] / p.h;
+            const float x = lx * p.w - 0.5f, y = ly * p.h - 0.5f;
+            if (y > -1 && x > -1 && y < p.h && x < p.w)
+                acc += (w8[l * 4 + pt] * inv) * msda_bilinear(vb, p.h, p.w, 256, y, x);
+        }
+    }
+    p.out[idx] = (bf16)acc;
+}
+
+int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s) {
+    const long total = (long)2 * a.h * a.w * 256;
+    hipLaunchKernelGGL(msda_fused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return 0;
+}

@@ -1,0 +1,339 @@
+// HBM-bound normalisation / depthwise kernels of the path (K1a and the LN/GN pieces of K2):
+//   layernorm_kernel   : row LN over C (convnext.py:176-184, nn.LayerNorm in deformable_transformer.py:98-119)
+//   gn_apply_kernel    : GroupNorm(G) from group sums + SiLU/ReLU (+ prior*beta fusion, unicorn_head.py:272-277)
+//   dwconv7_ln_kernel  : depthwise 7x7 + bias + LN fused (convnext.py:43-47)
+//   stem_kernel        : conv4x4/s4 + LN_cf on the NCHW input image (convnext.py:76-79)
+// All statistics in fp32 with a two-pass (mean, then centred variance) reduction; deterministic
+// (no float atomics).  NHWC everywhere so a wave's lanes walk the channel axis (coalesced 16-B accesses).
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row lives in registers (C <= 1536 -> <= 6 float4 per lane)
+// ------------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int C4 = p.C >> 2;
+    const float4* x = reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx);
+    float4 v[NI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int idx = lane + 64 * i;
+        v[i] = idx < C4 ? x[idx] : make_float4(0, 0, 0, 0);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int idx = lane + 64 * i;
+        if (idx < C4) {
+            float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / p.C + p.eps);
+    const float4* g4 = reinterpret_cast<const float4*>(p.gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(p.beta);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int idx = lane + 64 * i;
+        if (idx < C4) {
+            float4 g = g4[idx], b = b4[idx], o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if (p.outF) *reinterpret_cast<float4*>(p.outF + (size_t)row * p.ldf + idx * 4) = o;
+            if (p.outB) {
+                if (p.ps_h) {   // PixelShuffle(2) scatter: channel c=4*idx+{0..3} -> (dy,dx) = (j>>1, j&1), out ch idx
+                    int y = row / p.ps_w, xx = row - y * p.ps_w;
+                    int C4o = p.C >> 2, W2 = 2 * p.ps_w;
+                    bf16* ob = p.outB + ((size_t)(2 * y) * W2 + 2 * xx) * C4o + idx;
+                    ob[0] = (bf16)o.x;
+                    ob[C4o] = (bf16)o.y;
+                    ob[(size_t)W2 * C4o] = (bf16)o.z;
+                    ob[(size_t)W2 * C4o + C4o] = (bf16)o.w;
+                } else {
+                    bf16x4 ob = {(bf16)o.x, (bf16)o.y, (bf16)o.z, (bf16)o.w};
+                    *reinterpret_cast<bf16x4*>(p.outB + (size_t)row * p.ldb + idx * 4) = ob;
+                }
+            }
+        }
+    }
+}
+
+int launch_layernorm(const LnArgs& a, hipStream_t s) {
+    UNI_REQUIRE(a.C % 4 == 0 && a.C <= 1536 && a.ldx % 4 == 0, "layernorm: C=%d ldx=%d unsupported", a.C, a.ldx);
+    UNI_REQUIRE(((uintptr_t)a.x & 15) == 0, "layernorm: x not 16-B aligned");
+    int ni = cdiv(a.C / 4, 64);
+    dim3 grid(cdiv(a.M, 4)), block(256);
+    switch (ni) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, s, a); break;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm apply (stats were accumulated by the producing GEMM's epilogue)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
+    extern __shared__ float sm[];          // scale[C], shift[C]
+    float* scale = sm;
+    float* shift = sm + p.C;
+    const int cpg = p.C / p.G;
+    const double cnt = (double)p.M * cpg;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        int g = c / cpg;
+        double mean = p.stats[2 * g] / cnt;
+        double var = p.stats[2 * g + 1] / cnt - mean * mean;
+        float rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)p.eps));
+        float ga = p.gamma[c] * rstd;
+        scale[c] = ga;
+        shift[c] = p.beta[c] - (float)mean * ga;
+    }
+    __syncthreads();
+    const int C8 = p.C >> 3;
+    const long total = (long)p.M * C8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int m = (int)(e / C8);
+        int c = (int)(e - (long)m * C8) * 8;
+        const float4* xp = reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + c);
+        float4 a = xp[0], b = xp[1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float pr = p.prior ? p.prior[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = act_apply(v[j] * scale[c + j] + shift[c + j], p.act);
+            if (p.prior) y += pr * p.prior_beta[c + j];
+            v[j] = y;
+        }
+        if (p.outF) {
+            float4* op = reinterpret_cast<float4*>(p.outF + (size_t)m * p.ldf + c);
+            op[0] = make_float4(v[0], v[1], v[2], v[3]);
+            op[1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (p.outB || p.outUp) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+            if (p.outB) *reinterpret_cast<bf16x8*>(p.outB + (size_t)m * p.ldb + c) = o;
+            if (p.outUp) {
+                int y = m / p.W, x = m - y * p.W;
+                size_t W2 = 2 * (size_t)p.W;
+                bf16* u = p.outUp + ((size_t)(2 * y) * W2 + 2 * x) * p.ldu + c;
+                *reinterpret_cast<bf16x8*>(u) = o;
+                *reinterpret_cast<bf16x8*>(u + p.ldu) = o;
+                *reinterpret_cast<bf16x8*>(u + W2 * p.ldu) = o;
+                *reinterpret_cast<bf16x8*>(u + W2 * p.ldu + p.ldu) = o;
+            }
+        }
+    }
+}
+
+int launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
+    UNI_REQUIRE(a.C % 8 == 0 && a.C % a.G == 0 && a.ldx % 4 == 0, "gn_apply: C=%d G=%d ldx=%d", a.C, a.G, a.ldx);
+    if (a.outB) UNI_REQUIRE(a.ldb % 8 == 0 && ((uintptr_t)a.outB & 15) == 0, "gn_apply: outB alignment");
+    if (a.outUp) UNI_REQUIRE(a.ldu % 8 == 0 && ((uintptr_t)a.outUp & 15) == 0 && a.W > 0, "gn_apply: outUp alignment");
+    long total = (long)a.M * (a.C / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 2 * a.C * sizeof(float), s, a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic strip reduction shared by dwconv7_ln and stem:
+// thread (sl, cg) holds NV partial sums (its 4 channels) for the NV pixels of strip sl; returns the
+// per-pixel totals over all CG channel groups.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void strip_reduce(const float (&vals)[NV], float (&tot)[NV], float* lds, int S, int CG,
+                                             int sl, int cg, bool active) {
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int NP = S * NV;                 // (strip, pixel) pairs
+    const int R = (CG + 7) >> 3;           // slices of 8 channel groups
+    float* l1 = lds;                       // [NP][CG]
+    float* l2 = l1 + NP * CG;              // [NP][R]
+    float* l3 = l2 + NP * R;               // [NP]
+    if (active) {
+#pragma unroll
+        for (int o = 0; o < NV; ++o) l1[(sl * NV + o) * CG + cg] = vals[o];
+    }
+    __syncthreads();
+    for (int u = tid; u < NP * R; u += T) {
+        int pr = u / R, sc = u - pr * R;
+        int e = min(CG, sc * 8 + 8);
+        float s = 0.f;
+        for (int c = sc * 8; c < e; ++c) s += l1[pr * CG + c];
+        l2[u] = s;
+    }
+    __syncthreads();
+    for (int u = tid; u < NP; u += T) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += l2[u * R + r];
+        l3[u] = s;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int o = 0; o < NV; ++o) tot[o] = l3[sl * NV + o];
+    }
+    __syncthreads();
+}
+static size_t strip_reduce_lds(int S, int CG, int NV) {
+    int NP = S * NV, R = (CG + 7) / 8;
+    return (size_t)(NP * CG + NP * R + NP) * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 7x7 + bias + LayerNorm.  thread = (strip of 8 pixels along x, 4 channels); a 14-wide input
+// row window is held in registers and reused by the 7 kx taps (register sliding window).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int CG, int spr, int nstrips) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, sl = tid / CG;
+    const int strip = blockIdx.x * S + sl;
+    const bool active = sl < S && strip < nstrips;
+    const int y = active ? strip / spr : 0;
+    const int x0 = active ? (strip - y * spr) * 8 : 0;
+    const int C = p.C;
+    float4 acc[8];
+    {
+        float4 b = *reinterpret_cast<const float4*>(p.bias + cg * 4);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = b;
+    }
+    if (active) {
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = y + ky - 3;
+            if (iy < 0 || iy >= p.H) continue;
+            float4 in[14];
+            const float* rowp = p.x + ((size_t)iy * p.W) * C + cg * 4;
+#pragma unroll
+            for (int j = 0; j < 14; ++j) {
+                int ix = x0 + j - 3;
+                in[j] = (ix >= 0 && ix < p.W) ? *reinterpret_cast<const float4*>(rowp + (size_t)ix * C)
+                                              : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                float4 w = *reinterpret_cast<const float4*>(p.w + (size_t)(ky * 7 + kx) * C + cg * 4);
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    acc[o].x = fmaf(w.x, in[o + kx].x, acc[o].x);
+                    acc[o].y = fmaf(w.y, in[o + kx].y, acc[o].y);
+                    acc[o].z = fmaf(w.z, in[o + kx].z, acc[o].z);
+                    acc[o].w = fmaf(w.w, in[o + kx].w, acc[o].w);
+                }
+            }
+        }
+    }
+    float part[8], tot[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) part[o] = acc[o].x + acc[o].y + acc[o].z + acc[o].w;
+    strip_reduce<8>(part, tot, lds, S, CG, sl, cg, active);
+    float mean[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        mean[o] = tot[o] / C;
+        float a = acc[o].x - mean[o], b = acc[o].y - mean[o], c = acc[o].z - mean[o], d = acc[o].w - mean[o];
+        part[o] = a * a + b * b + c * c + d * d;
+    }
+    strip_reduce<8>(part, tot, lds, S, CG, sl, cg, active);
+    if (!active) return;
+    const float4 g = *reinterpret_cast<const float4*>(p.gamma + cg * 4);
+    const float4 be = *reinterpret_cast<const float4*>(p.beta + cg * 4);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (x0 + o < p.W) {
+            float rstd = 1.f / sqrtf(tot[o] / C + p.eps);
+            bf16x4 ob = {(bf16)((acc[o].x - mean[o]) * rstd * g.x + be.x), (bf16)((acc[o].y - mean[o]) * rstd * g.y + be.y),
+                         (bf16)((acc[o].z - mean[o]) * rstd * g.z + be.z), (bf16)((acc[o].w - mean[o]) * rstd * g.w + be.w)};
+            *reinterpret_cast<bf16x4*>(p.out + ((size_t)y * p.W + x0 + o) * C + cg * 4) = ob;
+        }
+    }
+}
+
+int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
+    UNI_REQUIRE(a.C % 4 == 0 && a.C / 4 <= 512, "dwconv7_ln: C=%d unsupported", a.C);
+    const int CG = a.C / 4;
+    int S = 256 / CG;
+    if (S < 1) S = 1;
+    const int spr = cdiv(a.W, 8), nstrips = spr * a.H;
+    const int T = cdiv(S * CG, 64) * 64;
+    hipLaunchKernelGGL(dwconv7_ln_kernel, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 8), s, a, S, CG, spr,
+                       nstrips);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: conv 4x4 / stride 4 (3 -> C) + bias + LN over C.  thread = (pixel, 4 out channels)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void stem_kernel(StemArgs p, int S, int CG, int npix) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, sl = tid / CG;
+    const int Wo = p.W >> 2;
+    const int pix = blockIdx.x * S + sl;
+    const bool active = sl < S && pix < npix;
+    float* patch = lds;                               // [S][48]
+    float* red = lds + S * 48;
+    // cooperative patch load: S*48 values, k = c*16 + ky*4 + kx
+    for (int u = tid; u < S * 48; u += blockDim.x) {
+        int sp = u / 48, k = u - sp * 48;
+        int px = blockIdx.x * S + sp;
+        float v = 0.f;
+        if (px < npix) {
+            int oy = px / Wo, ox = px - oy * Wo;
+            int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+            v = p.img[((size_t)c * p.H + oy * 4 + ky) * p.W + ox * 4 + kx];
+        }
+        patch[u] = v;
+    }
+    __syncthreads();
+    float4 acc = *reinterpret_cast<const float4*>(p.bias + cg * 4);
+    if (active) {
+#pragma unroll 8
+        for (int k = 0; k < 48; ++k) {
+            float4 w = *reinterpret_cast<const float4*>(p.w + (size_t)k * p.C + cg * 4);
+            float v = patch[sl * 48 + k];
+            acc.x = fmaf(w.x, v, acc.x);
+            acc.y = fmaf(w.y, v, acc.y);
+            acc.z = fmaf(w.z, v, acc.z);
+            acc.w = fmaf(w.w, v, acc.w);
+        }
+    }
+    float part[1] = {acc.x + acc.y + acc.z + acc.w}, tot[1];
+    strip_reduce<1>(part, tot, red, S, CG, sl, cg, active);
+    const float mean = tot[0] / p.C;
+    float a = acc.x - mean, b = acc.y - mean, c = acc.z - mean, d = acc.w - mean;
+    part[0] = a * a + b * b + c * c + d * d;
+    strip_reduce<1>(part, tot, red, S, CG, sl, cg, active);
+    if (!active) return;
+    const float rstd = 1.f / sqrtf(tot[0] / p.C + 1e-6f);
+    const float4 g = *reinterpret_cast<const float4*>(p.gamma + cg * 4);
+    const float4 be = *reinterpret_cast<const float4*>(p.beta + cg * 4);
+    float4 o = make_float4(a * rstd * g.x + be.x, b * rstd * g.y + be.y, c * rstd * g.z + be.z, d * rstd * g.w + be.w);
+    *reinterpret_cast<float4*>(p.out + (size_t)pix * p.C + cg * 4) = o;
+}
+
+int launch_stem(const StemArgs& a, hipStream_t s) {
+    UNI_REQUIRE(a.C % 4 == 0 && a.H % 4 == 0 && a.W % 4 == 0, "stem: C=%d H=%d W=%d unsupported", a.C, a.H, a.W);
+    const int CG = a.C / 4;
+    int S = 256 / CG;
+    if (S < 1) S = 1;
+    const int npix = (a.H / 4) * (a.W / 4);
+    const int T = cdiv(S * CG, 64) * 64;
+    size_t lds = S * 48 * sizeof(float) + strip_reduce_lds(S, CG, 1);
+    hipLaunchKernelGGL(stem_kernel, dim3(cdiv(npix, S)), dim3(T), lds, s, a, S, CG, npix);
+    return 0;
+}

@@ -1,0 +1,300 @@
+"""Drop-in for ``unicorn.models.Unicorn`` (inference modes only) running on libunicorn_hip.so.
+
+API mirrored from the reference (paths relative to MasterBin-IIAU/Unicorn):
+  Unicorn.forward(mode="backbone"|"interaction"|"upsample"|"whole")   unicorn/models/unicorn.py:60-74,133-139
+  model.head(fpn_outs, priors, mode="sot"|"mot")                       unicorn_head.py:249 / unicorn_head_mask.py:280
+  model.head.mask_head(mask_feats, 8, mask_head_params=..., ...)       condinst/dynamic_mask_head.py:227-285
+  model.load_state_dict(sd, strict=False) -> (missing_keys, unexpected_keys), .eval(), .cuda(), .half()
+Tensors returned to the caller are ordinary torch tensors of the reference's NCHW *shape*; their memory
+is channels_last (NHWC), which is what the HIP kernels produce/consume, so round trips are copy-free.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..ops import condinst_masks, empty_nhwc, nhwc
+
+_IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+# exps/default/*.py + unicorn/exp/unicorn_track.py:31-113, unicorn_track_mask.py:31-47
+MODEL_CONFIGS = {
+    "unicorn_track_tiny": dict(dims=(96, 192, 384, 768), depths=(3, 3, 9, 3), num_classes=8, mask=False),
+    "unicorn_track_tiny_mask": dict(dims=(96, 192, 384, 768), depths=(3, 3, 9, 3), num_classes=8, mask=True),
+    "unicorn_track_large": dict(dims=(192, 384, 768, 1536), depths=(3, 3, 27, 3), num_classes=8, mask=False),
+    "unicorn_track_large_mask": dict(dims=(192, 384, 768, 1536), depths=(3, 3, 27, 3), num_classes=8, mask=True),
+    "unicorn_track_large_mot_challenge": dict(dims=(192, 384, 768, 1536), depths=(3, 3, 27, 3), num_classes=1, mask=False),
+    "unicorn_track_large_mot_challenge_mask": dict(dims=(192, 384, 768, 1536), depths=(3, 3, 27, 3), num_classes=1, mask=True),
+}
+
+
+class DynamicMaskHead:
+    """condinst/dynamic_mask_head.py: callable returning sigmoid mask scores (N,1,up_rate*H8,up_rate*W8)."""
+
+    def __init__(self, up_rate):
+        self.up_rate = up_rate
+        self.training = False
+
+    def __call__(self, mask_feats, mask_feat_stride, mask_head_params=None, instance_locations=None,
+                 instance_fpn_levels=None, gt_bitmasks=None, up_masks=None):
+        if mask_feat_stride != 8 or up_masks is None:
+            raise ValueError("DynamicMaskHead: only mask_feat_stride=8 with RAFT up_masks is supported (use_raft=True)")
+        return condinst_masks(mask_feats, up_masks, mask_head_params, instance_locations, instance_fpn_levels,
+                              self.up_rate, 1)
+
+
+class UnicornHead:
+    """unicorn_head.py:19-482 (eval branch). Owned by Unicorn; shares its context."""
+
+    def __init__(self, model):
+        self._m = model
+        self.num_classes = model.num_classes
+        self.num_classes_sot = 1
+        self.decode_in_inference = True
+        self.strides = [8, 16, 32]
+        self.training = False
+        self.hw = None
+
+    def __call__(self, xin, mask_in, labels=None, imgs=None, mode=None, **kw):
+        return self.forward(xin, mask_in, mode=mode)
+
+    def _run(self, xin, mask_in, mode):
+        if mode not in ("sot", "mot"):
+            raise ValueError("""mode has to be 'sot' or 'mot'""")        # unicorn_head.py:292
+        if not self.decode_in_inference:
+            raise ValueError("decode_in_inference=False is not supported")
+        m = self._m
+        m._require_ready()
+        f = [nhwc(x) for x in xin]
+        H, W = f[0].shape[2] * 8, f[0].shape[3] * 8
+        pri = []
+        for k, p in enumerate(mask_in):
+            if p.shape[1] != 1 or p.shape[0] != 1:
+                raise ValueError("head: priors must be (1,1,H/s,W/s); run one object per call like the reference drivers")
+            pri.append(p.float().contiguous())
+        nc = 1 if mode == "sot" else self.num_classes
+        A = sum(x.shape[2] * x.shape[3] for x in f)
+        dev = f[0].device
+        out = torch.empty((1, A, 5 + nc), device=dev, dtype=torch.float32)
+        dyn = mf = um = None
+        if m.mask:
+            dyn = torch.empty((1, A, 169), device=dev, dtype=torch.float32)
+            mf = empty_nhwc(8, H // 8, W // 8, dev)
+            um = empty_nhwc(9 * m.up_rate ** 2, H // 8, W // 8, dev)
+        L.check(L.lib().uni_head(m._ctx, L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(pri[0]), L.ptr(pri[1]), L.ptr(pri[2]),
+                                 H, W, 0 if mode == "sot" else 1, L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
+                                 L.stream_ptr()), "uni_head")
+        self.hw = [tuple(x.shape[2:]) for x in f]
+        return out, dyn, mf, um
+
+    def forward(self, xin, mask_in, mode=None):
+        return self._run(xin, mask_in, mode)[0]
+
+    def decode_outputs(self, outputs, dtype=None):
+        """unicorn_head.py:467-482 on raw (B,A,5+nc) outputs (in place)."""
+        grids, strides = self._m._grids(self.hw, outputs.device)
+        outputs[..., :2] = (outputs[..., :2] + grids) * strides
+        outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * strides
+        return outputs
+
+
+class UnicornHeadMask(UnicornHead):
+    """unicorn_head_mask.py:22-519 (eval branch) -> (outputs, locations, dynamic_params, fpn_levels, mask_feats, up_masks)."""
+
+    def __init__(self, model):
+        super().__init__(model)
+        self.mask_head = DynamicMaskHead(model.up_rate)
+
+    def forward(self, xin, mask_in, mode=None):
+        out, dyn, mf, um = self._run(xin, mask_in, mode)
+        grids, strides = self._m._grids(self.hw, out.device)
+        locations = ((grids + 0.5) * strides)[0]                               # unicorn_head_mask.py:518
+        levels = torch.cat([torch.full((1, h * w), k) for k, (h, w) in enumerate(self.hw)], 1)   # CPU like the reference
+        return out, locations, dyn, levels, mf, um
+
+
+class Unicorn:
+    def __init__(self, name_or_cfg="unicorn_track_tiny", device=None):
+        cfg = dict(MODEL_CONFIGS[name_or_cfg]) if isinstance(name_or_cfg, str) else dict(name_or_cfg)
+        self.cfg_name = name_or_cfg if isinstance(name_or_cfg, str) else "custom"
+        self.dims, self.depths = tuple(cfg["dims"]), tuple(cfg["depths"])
+        self.num_classes, self.mask = int(cfg["num_classes"]), bool(cfg["mask"])
+        self.n_layer_att = int(cfg.get("n_layer_att", 3))
+        self.embed_dim = int(cfg.get("embed_dim", 128))
+        self.d_rate = int(cfg.get("d_rate", 2))
+        self.up_rate = 8 // self.d_rate
+        self.interact_mode = "deform"
+        self.training = False
+        self._ctx = None
+        self._ready = False
+        self._device = None
+        self._pos_cache = {}
+        self._grid_cache = {}
+        self.head = UnicornHeadMask(self) if self.mask else UnicornHead(self)
+        if device is not None:
+            self.cuda(device)
+
+    # ---------------------------------------------------------------- nn.Module-like surface
+    def cuda(self, device=None):
+        if not torch.cuda.is_available():
+            raise L.UnicornHipError("unicorn_amd needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+        idx = torch.cuda.current_device() if device is None else torch.device("cuda", device).index if isinstance(device, int) \
+            else torch.device(device).index
+        idx = 0 if idx is None else idx
+        if self._ctx is not None and self._device is not None and self._device.index != idx:
+            raise L.UnicornHipError("model already bound to %s" % self._device)
+        self._device = torch.device("cuda", idx)
+        if self._ctx is None:
+            c = L.ModelCfg()
+            c.dims[:] = self.dims
+            c.depths[:] = self.depths
+            c.num_classes, c.mask, c.n_layer_att = self.num_classes, int(self.mask), self.n_layer_att
+            c.embed_dim, c.up_rate, c.d_rate = self.embed_dim, self.up_rate, self.d_rate
+            ctx = L.lib().uni_ctx_create(idx, C.byref(c))
+            if not ctx:
+                raise L.UnicornHipError("uni_ctx_create: %s" % L.lib().uni_last_error().decode())
+            self._ctx = C.c_void_p(ctx)
+            if getattr(self, "_pending_sd", None) is not None:
+                sd, self._pending_sd = self._pending_sd, None
+                self._load(sd)
+        return self
+
+    def to(self, device):
+        return self.cuda(device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise L.UnicornHipError("unicorn_amd implements the inference path only")
+        return self
+
+    def half(self):
+        # tools/track.py --fp16 calls model.half(); the HIP path already computes in bf16 MFMA / fp32 accumulate
+        return self
+
+    def float(self):
+        return self
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                L.lib().uni_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Same contract as nn.Module.load_state_dict; keys follow the reference checkpoint namespace."""
+        if self._ready:
+            raise L.UnicornHipError("weights already loaded (the packed device copy is immutable)")
+        if self._ctx is None:
+            self._pending_sd = state_dict
+            return _IncompatibleKeys([], [])
+        return self._load(state_dict, strict)
+
+    def _load(self, state_dict, strict=False):
+        lib = L.lib()
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            a = np.ascontiguousarray(v.detach().float().cpu().numpy())
+            shp = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            L.check(lib.uni_ctx_load_param(self._ctx, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim), "load_param")
+        nm = C.c_int(0)
+        L.check(lib.uni_ctx_finalize(self._ctx, C.byref(nm)), "uni_ctx_finalize")
+        missing = [lib.uni_ctx_missing_name(self._ctx, i).decode() for i in range(nm.value)]
+        if strict and missing:
+            raise RuntimeError("Error(s) in loading state_dict: missing keys %s" % missing[:8])
+        self._ready = True
+        return _IncompatibleKeys(missing, [])
+
+    def _require_ready(self):
+        if self._ctx is None:
+            raise L.UnicornHipError("call model.cuda() first (unicorn_amd has no CPU path)")
+        if not self._ready:
+            raise L.UnicornHipError("load_state_dict() must be called before running the model")
+
+    # ---------------------------------------------------------------- helpers
+    def _grids(self, hw, device):
+        key = (tuple(hw), str(device))
+        if key not in self._grid_cache:
+            grids, strides = [], []
+            for (h, w), s in zip(hw, (8, 16, 32)):
+                yv, xv = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+                grids.append(torch.stack((xv, yv), 2).view(1, -1, 2).float())
+                strides.append(torch.full((1, h * w, 1), float(s)))
+            self._grid_cache[key] = (torch.cat(grids, 1).to(device), torch.cat(strides, 1).to(device))
+        return self._grid_cache[key]
+
+    def _pos(self, h, w):
+        key = (h, w)
+        if key not in self._pos_cache:      # constant per resolution
+            p = empty_nhwc(256, h, w, self._device)
+            L.check(L.lib().uni_pos_embed(self._ctx, h, w, L.ptr(p), L.stream_ptr()), "uni_pos_embed")
+            self._pos_cache[key] = p
+        return self._pos_cache[key]
+
+    # ---------------------------------------------------------------- forward modes
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, imgs=None, run_fpn=True, seq_dict0=None, seq_dict1=None, feat=None, mode="whole", **unused):
+        if mode == "backbone":
+            return self.forward_backbone(imgs, run_fpn)
+        elif mode == "interaction":
+            return self.forward_deform_interact(seq_dict0, seq_dict1)
+        elif mode == "upsample":
+            return self.forward_upsample(feat)
+        elif mode == "whole":                                              # unicorn.py:133-139
+            bs, _, H, W = imgs.size()
+            fpn_outs, seq_dict = self.forward_backbone(imgs, run_fpn=True)
+            dev = fpn_outs[0].device
+            pri = tuple(torch.zeros((bs, 1, H // s, W // s), device=dev) for s in (8, 16, 32))
+            return self.head(fpn_outs, pri, mode="mot"), seq_dict
+        else:
+            raise ValueError                                               # unicorn.py:229
+
+    def forward_backbone(self, img, run_fpn=True):
+        assert isinstance(img, torch.Tensor)
+        self._require_ready()
+        if img.dim() != 4 or img.shape[0] != 1 or img.shape[1] != 3:
+            raise ValueError("forward_backbone expects a (1,3,H,W) image batch (drivers run -b 1)")
+        if not img.is_cuda:
+            raise L.UnicornHipError("input image must be a HIP device tensor; no CPU fallback")
+        x = img.float().contiguous()
+        _, _, H, W = x.shape
+        dev = x.device
+        c1, c2, c3 = self.dims[1:]
+        fpn = (empty_nhwc(c1, H // 8, W // 8, dev), empty_nhwc(c2, H // 16, W // 16, dev), empty_nhwc(c3, H // 32, W // 32, dev))
+        feat16 = empty_nhwc(c2, H // 16, W // 16, dev)
+        L.check(L.lib().uni_backbone_fpn(self._ctx, L.ptr(x), H, W, L.ptr(fpn[0]), L.ptr(fpn[1]), L.ptr(fpn[2]), L.ptr(feat16),
+                                         L.stream_ptr()), "uni_backbone_fpn")
+        h, w = H // 16, W // 16
+        seq_dict = {"feat": feat16, "pos": self._pos(h, w), "h": h, "w": w}
+        return (fpn, seq_dict) if run_fpn else seq_dict
+
+    def forward_deform_interact(self, d0, d1):
+        self._require_ready()
+        f0, f1, p0, p1 = nhwc(d0["feat"]), nhwc(d1["feat"]), nhwc(d0["pos"]), nhwc(d1["pos"])
+        h, w = d0["h"], d0["w"]
+        if tuple(f1.shape) != tuple(f0.shape):
+            raise ValueError("interaction: reference and current feature maps must have the same shape")
+        o0, o1 = empty_nhwc(256, h, w, f0.device), empty_nhwc(256, h, w, f0.device)
+        L.check(L.lib().uni_interaction(self._ctx, L.ptr(f0), L.ptr(p0), L.ptr(f1), L.ptr(p1), h, w, L.ptr(o0), L.ptr(o1),
+                                        L.stream_ptr()), "uni_interaction")
+        return o0, o1
+
+    def forward_upsample(self, x):
+        self._require_ready()
+        f = nhwc(x)
+        _, c, h, w = f.shape
+        if c != 256:
+            raise ValueError("upsample expects a 256-channel map")
+        e = empty_nhwc(self.embed_dim, 2 * h, 2 * w, f.device)
+        L.check(L.lib().uni_upsample(self._ctx, L.ptr(f), h, w, L.ptr(e), L.stream_ptr()), "uni_upsample")
+        return e

@@ -1,0 +1,113 @@
+"""Thin tensor-level wrappers over the C-ABI operators (torch only allocates and hands over pointers)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.UnicornHipError("unicorn_amd ops need HIP device tensors (got a CPU tensor); there is no CPU fallback")
+
+
+def nhwc(t):
+    """(1,C,H,W) tensor -> fp32 tensor whose memory is [H][W][C] (channels_last), no copy when already so."""
+    t = t.float() if t.dtype != torch.float32 else t
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(c, h, w, device):
+    return torch.empty((1, c, h, w), device=device, dtype=torch.float32, memory_format=torch.channels_last)
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step=64):
+    """Same signature as MultiScaleDeformableAttention.ms_deform_attn_forward (ops/src/vision.cpp:13-16)."""
+    _need_cuda(value, sampling_locations, attention_weights)
+    if value.dtype != torch.float32:
+        raise L.UnicornHipError("msda_forward: only fp32 is implemented (reference dispatches fp32/fp64)")
+    value, loc, attn = value.contiguous(), sampling_locations.contiguous(), attention_weights.contiguous()
+    N, S, M, D = value.shape
+    _, Lq, _, Ln, P, _ = loc.shape
+    shp = (C.c_int64 * (2 * Ln))(*[int(v) for v in spatial_shapes.reshape(-1).tolist()])
+    lsi = (C.c_int64 * Ln)(*[int(v) for v in level_start_index.reshape(-1).tolist()])
+    out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
+    L.check(L.lib().uni_msda_fwd(L.ptr(value), shp, lsi, L.ptr(loc), L.ptr(attn), L.ptr(out), N, S, M, D, Lq, Ln, P,
+                                 L.stream_ptr()), "uni_msda_fwd")
+    return out
+
+
+_corr_ws = {}
+
+
+def corr_softmax_pv(embed_ref, embed_cur, values, precision=0):
+    """embed_* : (C, HW) (any strides; an NHWC map viewed as (C,HW) needs no copy) ; values (K, HW_ref) -> (K, HW_cur).
+    == values @ softmax(embed_ref^T @ embed_cur, dim=0)   (unicorn_sot.py:95-100)"""
+    _need_cuda(embed_ref, embed_cur, values)
+    er = embed_ref.float().t().contiguous()     # (HW, C) row-major
+    ec = embed_cur.float().t().contiguous()
+    v = values.float().contiguous()
+    R, D = er.shape
+    Q = ec.shape[0]
+    K = v.shape[0]
+    out = torch.empty((K, Q), device=er.device, dtype=torch.float32)
+    need = L.lib().uni_corr_workspace_bytes(R, Q, K)
+    key = (er.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _corr_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1), device=er.device, dtype=torch.uint8)
+        _corr_ws[key] = ws
+    L.check(L.lib().uni_corr_softmax_pv(L.ptr(er), L.ptr(ec), L.ptr(v), L.ptr(out), R, Q, D, K, precision, L.ptr(ws),
+                                        ws.numel(), L.stream_ptr()), "uni_corr_softmax_pv")
+    return out
+
+
+def prior_pyramid(coarse):
+    """(1,K,H8,W8) -> (coarse, 1/2, 1/4) like unicorn_sot.py:103-105"""
+    _need_cuda(coarse)
+    c = coarse.float().contiguous()
+    _, K, H8, W8 = c.shape
+    p16 = torch.empty((1, K, H8 // 2, W8 // 2), device=c.device, dtype=torch.float32)
+    p32 = torch.empty((1, K, H8 // 4, W8 // 4), device=c.device, dtype=torch.float32)
+    L.check(L.lib().uni_prior_pyramid(L.ptr(c), L.ptr(p16), L.ptr(p32), K, H8, W8, L.stream_ptr()), "uni_prior_pyramid")
+    return c, p16, p32
+
+
+def label_map_s8(box_xyxy, H, W, device):
+    b = torch.as_tensor(box_xyxy, dtype=torch.float32).reshape(4).to(device)
+    out = torch.empty((1, (H // 8) * (W // 8)), device=device, dtype=torch.float32)
+    L.check(L.lib().uni_label_map_s8(L.ptr(b), L.ptr(out), H, W, L.stream_ptr()), "uni_label_map_s8")
+    return out
+
+
+def sample_embeddings(embed, boxes_xyxy, stride=8.0):
+    """embed (1,C,H8,W8); boxes (N,>=4) xyxy in input pixels -> (N,C)  (mot_evaluator.py:1024-1034)"""
+    _need_cuda(embed, boxes_xyxy)
+    e = nhwc(embed)
+    _, Cc, H8, W8 = e.shape
+    b = boxes_xyxy.float().contiguous()
+    n = b.shape[0]
+    out = torch.empty((n, Cc), device=e.device, dtype=torch.float32)
+    if n:
+        L.check(L.lib().uni_sample_embeddings(L.ptr(e), H8, W8, Cc, L.ptr(b), b.shape[1], n, float(stride), L.ptr(out),
+                                              L.stream_ptr()), "uni_sample_embeddings")
+    return out
+
+
+def condinst_masks(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_rate):
+    """-> (N,1,d_rate*up_rate*H8, d_rate*up_rate*W8) sigmoid scores"""
+    _need_cuda(mask_feats, up_masks, params)
+    mf, um = nhwc(mask_feats), nhwc(up_masks)
+    _, _, H8, W8 = mf.shape
+    p = params.float().contiguous()
+    n = p.shape[0]
+    loc = inst_loc.float().contiguous().to(mf.device)
+    lvl = inst_lvl.to(device=mf.device, dtype=torch.int32).contiguous()
+    out = torch.empty((n, 1, d_rate * up_rate * H8, d_rate * up_rate * W8), device=mf.device, dtype=torch.float32)
+    if n:
+        ws = torch.empty(n * H8 * W8 * (1 + up_rate * up_rate), device=mf.device, dtype=torch.float32)
+        L.check(L.lib().uni_condinst_masks(L.ptr(mf), L.ptr(um), L.ptr(p), p.shape[1], L.ptr(loc), L.ptr(lvl), n, H8, W8,
+                                           up_rate, d_rate, L.ptr(out), L.ptr(ws), ws.numel() * 4, L.stream_ptr()),
+                "uni_condinst_masks")
+    return out
