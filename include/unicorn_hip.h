@@ -46,7 +46,7 @@ extern "C" {
 typedef struct uni_ctx uni_ctx;
 typedef void* uni_stream_t; /* hipStream_t */
 
-/* Network shape, mirrors exp/unicorn_track.py:31-113 + exps/default/*.py */
+/* Network shape, mirrors exp/unicorn_track.py:31-113 + exps/default/ *.py */
 typedef struct uni_model_cfg {
     int32_t dims[4];     /* ConvNeXt stage widths: tiny 96,192,384,768 / large 192,384,768,1536 */
     int32_t depths[4];   /* 3,3,9,3 / 3,3,27,3 */
@@ -74,6 +74,12 @@ int uni_ctx_finalize(uni_ctx* ctx, int* n_missing);
 const char* uni_ctx_missing_name(uni_ctx* ctx, int i);
 /* Pre-size the scratch workspace for an (H,W) input (optional; grows on demand otherwise). */
 int uni_ctx_reserve(uni_ctx* ctx, int H, int W);
+
+/* Per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg, off by default).
+ * uni_prof_end synchronises the device and fills out15 = [5 classes][ms, work, launches]; classes: 0 GEMM/conv
+ * (work = algorithmic FLOPs 2*M*N*K), 1 dwconv7+LN, 2 GroupNorm apply, 3 LayerNorm (work = algorithmic bytes), 4 misc. */
+int uni_prof_begin(uni_ctx* ctx);
+int uni_prof_end(uni_ctx* ctx, double* out15);
 
 /* ---- stage entry points (one per Unicorn.forward mode) ----------------------------------------------- */
 /* img: (1,3,H,W) fp32 NCHW.  fpn{0,1,2}: NHWC fp32 (H/8,W/8,C1), (H/16,W/16,C2), (H/32,W/32,C3).

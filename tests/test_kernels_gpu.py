@@ -78,8 +78,10 @@ def test_gemm_conv(L, cfg, case):
     outF = torch.full((M, N), float("nan"), device="cuda")
     outB = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
     stats = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
+    bias_d = dev(bias) if use_bias else None
+    res_d = dev(res) if use_res else None
     L.check(L.lib().uni_gemm_bf16(L.ptr(A), Cin, L.ptr(Wp), M, N, Hin, Win, Cin, k, k, stride, pad,
-                                  L.ptr(dev(bias)) if use_bias else None, act, L.ptr(dev(res)) if use_res else None, N,
+                                  L.ptr(bias_d), act, L.ptr(res_d), N,
                                   L.ptr(outF), N, L.ptr(outB), N, L.ptr(stats), (N // G) if G else 0, cfg, L.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     got = outF.cpu()
@@ -108,7 +110,8 @@ def test_gemm_act_col0(L):
     lib = L.lib()
     # act_col0 is only reachable through the engine; emulate with two calls is not possible -> call engine-level check in
     # test_model_gpu; here check ragged ldf writes leave the 6th column untouched
-    L.check(lib.uni_gemm_bf16(L.ptr(as_u16(x).cuda()), K, L.ptr(pack_weight(L, w)), M, N, M, 1, K, 1, 1, 1, 0, L.ptr(b.cuda()), 0,
+    xd, wd, bd = as_u16(x).cuda(), pack_weight(L, w), b.cuda()
+    L.check(lib.uni_gemm_bf16(L.ptr(xd), K, L.ptr(wd), M, N, M, 1, K, 1, 1, 1, 0, L.ptr(bd), 0,
                               None, 0, L.ptr(out), 6, None, 0, None, 0, 0, L.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     assert (out[:, :5].cpu() - raw).abs().max() < 2e-3 * raw.abs().max()
@@ -124,7 +127,8 @@ def test_layernorm(L, C_):
     exp = F.layer_norm(x, (C_,), ga, be, 1e-6)
     outF = torch.empty((M, C_), device="cuda")
     outB = torch.empty((M, C_), device="cuda", dtype=torch.bfloat16)
-    L.check(L.lib().uni_layernorm(L.ptr(x.cuda()), C_, L.ptr(ga.cuda()), L.ptr(be.cuda()), 1e-6, M, C_, L.ptr(outF), L.ptr(outB),
+    xd, gd, bd = x.cuda(), ga.cuda(), be.cuda()
+    L.check(L.lib().uni_layernorm(L.ptr(xd), C_, L.ptr(gd), L.ptr(bd), 1e-6, M, C_, L.ptr(outF), L.ptr(outB),
                                   L.stream_ptr()), "ln")
     torch.cuda.synchronize()
     assert (outF.cpu() - exp).abs().max() < 2e-5 * exp.abs().max()
@@ -143,7 +147,8 @@ def test_dwconv7_ln(L, shape):
     xn = x.permute(0, 2, 3, 1).contiguous().cuda()
     wt = w.reshape(C_, 49).t().contiguous().cuda()
     out = torch.empty((H * W, C_), device="cuda", dtype=torch.bfloat16)
-    L.check(L.lib().uni_dwconv7_ln(L.ptr(xn), L.ptr(wt), L.ptr(b.cuda()), L.ptr(ga.cuda()), L.ptr(be.cuda()), 1e-6, H, W, C_,
+    bd, gd, bed = b.cuda(), ga.cuda(), be.cuda()
+    L.check(L.lib().uni_dwconv7_ln(L.ptr(xn), L.ptr(wt), L.ptr(bd), L.ptr(gd), L.ptr(bed), 1e-6, H, W, C_,
                                    L.ptr(out), L.stream_ptr()), "dwln")
     torch.cuda.synchronize()
     err = (out.float().cpu() - exp).abs().max().item()
@@ -162,7 +167,8 @@ def test_groupnorm_act(L, C_, G, act):
     grp = x.reshape(M, G, C_ // G).double()
     stats = torch.stack([grp.sum((0, 2)), (grp ** 2).sum((0, 2))], 1).reshape(-1).cuda()
     outF = torch.empty((M, C_), device="cuda")
-    L.check(L.lib().uni_groupnorm_act(L.ptr(x.cuda()), L.ptr(stats), L.ptr(ga.cuda()), L.ptr(be.cuda()), eps, M, C_, G, act,
+    xd, gd, bd = x.cuda(), ga.cuda(), be.cuda()
+    L.check(L.lib().uni_groupnorm_act(L.ptr(xd), L.ptr(stats), L.ptr(gd), L.ptr(bd), eps, M, C_, G, act,
                                       L.ptr(outF), None, L.stream_ptr()), "gn")
     torch.cuda.synchronize()
     assert (outF.cpu() - exp).abs().max() < 1e-4 * max(1.0, exp.abs().max().item())
@@ -178,7 +184,8 @@ def test_stem(L, C_):
     exp = uo.ln_channels_first(F.conv2d(img, w, b, stride=4), ga, be).permute(0, 2, 3, 1).reshape(-1, C_)
     wt = w.reshape(C_, 48).t().contiguous().cuda()
     out = torch.empty((H // 4 * W // 4, C_), device="cuda")
-    L.check(L.lib().uni_stem(L.ptr(img.cuda()), H, W, L.ptr(wt), L.ptr(b.cuda()), L.ptr(ga.cuda()), L.ptr(be.cuda()), C_, L.ptr(out),
+    imd, bd, gd, bed = img.cuda(), b.cuda(), ga.cuda(), be.cuda()
+    L.check(L.lib().uni_stem(L.ptr(imd), H, W, L.ptr(wt), L.ptr(bd), L.ptr(gd), L.ptr(bed), C_, L.ptr(out),
                              L.stream_ptr()), "stem")
     torch.cuda.synchronize()
     assert (out.cpu() - exp).abs().max() < 2e-4 * max(1.0, exp.abs().max().item())

@@ -16,6 +16,8 @@ struct PBlock { float* dw_w = nullptr; float* dw_b = nullptr; PAffine ln; PConv 
 struct PBaseConv { PConv conv; PAffine gn; int k = 1, stride = 1; };
 struct PCsp { PConv c12; PAffine gn12; PBaseConv m1[3], m2[3], c3; int cin = 0, cout = 0, h = 0; };
 
+struct ProfRec { hipEvent_t a, b; double work; int cls; };
+
 struct uni_ctx {
     int device = 0;
     uni_model_cfg cfg{};
@@ -45,12 +47,15 @@ struct uni_ctx {
     // scratch
     char* ws = nullptr; size_t ws_cap = 0, ws_off = 0; bool ws_overflow = false;
     double* stats = nullptr; int stats_slot = 0;
+    bool prof_on = false; std::vector<ProfRec> recs;
 };
 
 uint16_t f32_to_bf16_host(float f);
 void pack_weight_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, uint16_t* out, int Npad, int Kpad);
 int engine_finalize(uni_ctx* c);
 int engine_reserve(uni_ctx* c, int H, int W);
+int engine_prof_begin(uni_ctx* c);
+int engine_prof_end(uni_ctx* c, double* out);
 void engine_destroy(uni_ctx* c);
 int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16, hipStream_t s);
 int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,

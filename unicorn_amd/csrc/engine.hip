@@ -313,6 +313,57 @@ static double* next_stats(uni_ctx* c) {
 }
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; if (c->ws_overflow) return -3; } while (0)
 
+
+// ------------------------------------------------------------------------------------------------
+// optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
+// ------------------------------------------------------------------------------------------------
+enum { PC_GEMM = 0, PC_DWLN = 1, PC_GN = 2, PC_LN = 3, PC_MISC = 4, PC_NCLS = 5 };
+template <class F>
+static int prof_run(uni_ctx* c, int cls, double work, hipStream_t s, F&& f) {
+    if (!c->prof_on) return f();
+    ProfRec r;
+    r.cls = cls; r.work = work;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return f();
+    (void)hipEventRecord(r.a, s);
+    int rc = f();
+    (void)hipEventRecord(r.b, s);
+    c->recs.push_back(r);
+    return rc;
+}
+static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
+    return prof_run(c, PC_GEMM, 2.0 * g.M * g.N * g.K, s, [&] { return launch_gemm(g, s); });
+}
+static int p_dwln(uni_ctx* c, const DwLnArgs& d, hipStream_t s) {
+    return prof_run(c, PC_DWLN, (double)d.H * d.W * d.C * 6.0 + 49.0 * d.C * 4, s, [&] { return launch_dwconv7_ln(d, s); });
+}
+static int p_gn(uni_ctx* c, const GnApplyArgs& a, hipStream_t s) {
+    double b = (double)a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0) + (a.outUp ? 8 : 0));
+    return prof_run(c, PC_GN, b, s, [&] { return launch_gn_apply(a, s); });
+}
+static int p_ln(uni_ctx* c, const LnArgs& a, hipStream_t s) {
+    double b = (double)a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0));
+    return prof_run(c, PC_LN, b, s, [&] { return launch_layernorm(a, s); });
+}
+int engine_prof_begin(uni_ctx* c) {
+    for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    c->recs.clear();
+    c->prof_on = true;
+    return 0;
+}
+int engine_prof_end(uni_ctx* c, double* out) {   // out[PC_NCLS][3] = {ms, work, launches}
+    c->prof_on = false;
+    UNI_CHECK_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < PC_NCLS * 3; ++i) out[i] = 0.0;
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        out[r.cls * 3 + 0] += ms; out[r.cls * 3 + 1] += r.work; out[r.cls * 3 + 2] += 1;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    c->recs.clear();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------
@@ -341,14 +392,14 @@ static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, 
     float* raw = wsalloc<float>(c, (size_t)g.M * g.N);
     double* st = next_stats(c);
     g.outF = raw; g.ldf = g.N; g.stats = st; g.cpg = g.N / G;
-    RUN(launch_gemm(g, s));
+    RUN(p_gemm(c, g, s));
     GnApplyArgs a;
     a.x = raw; a.ldx = g.N; a.stats = st; a.gamma = gn.g; a.beta = gn.b; a.eps = eps;
     a.M = g.M; a.C = g.N; a.G = G; a.act = act;
     a.prior = o.prior; a.prior_beta = o.pbeta;
     a.outF = o.F; a.ldf = o.ldf; a.outB = o.B; a.ldb = o.ldb; a.outUp = o.Up; a.ldu = o.ldu;
     a.W = (Win + 2 * ((conv.KW - 1) / 2) - conv.KW) / stride + 1;
-    RUN(launch_gn_apply(a, s));
+    RUN(p_gn(c, a, s));
     c->ws_off = mark;     // raw is dead once gn_apply is enqueued (single in-order stream)
     return 0;
 }
@@ -362,13 +413,13 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, bf16* 
     DwLnArgs d;
     d.x = x; d.w = b.dw_w; d.bias = b.dw_b; d.gamma = b.ln.g; d.beta = b.ln.b; d.eps = 1e-6f;
     d.H = H; d.W = W; d.C = C; d.out = t;
-    RUN(launch_dwconv7_ln(d, s));
+    RUN(p_dwln(c, d, s));
     GemmArgs g1 = conv_args(b.pw1, t, C, M, 1, 1, 0);
     g1.act = ACT_GELU; g1.outB = hid; g1.ldb = 4 * C;
-    RUN(launch_gemm(g1, s));
+    RUN(p_gemm(c, g1, s));
     GemmArgs g2 = conv_args(b.pw2, hid, 4 * C, M, 1, 1, 0);
     g2.res = x; g2.ldr = C; g2.outF = x; g2.ldf = C; g2.outB = outB; g2.ldb = C;
-    RUN(launch_gemm(g2, s));
+    RUN(p_gemm(c, g2, s));
     return 0;
 }
 
@@ -419,7 +470,7 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
         StemArgs st;
         st.img = img; st.H = H; st.W = W; st.w = c->stem_w; st.bias = c->stem_b; st.gamma = c->stem_ln.g; st.beta = c->stem_ln.b;
         st.C = d[0]; st.out = x;
-        RUN(launch_stem(st, s));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_stem(st, s); }));
         for (int i = 0; i < 4; ++i) {
             if (i > 0) {
                 // LN_cf + conv2x2/s2 (convnext.py:80-86)
@@ -427,11 +478,11 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
                 LnArgs ln;
                 ln.x = x; ln.ldx = d[i - 1]; ln.gamma = c->ds_ln[i].g; ln.beta = c->ds_ln[i].b; ln.eps = 1e-6f;
                 ln.M = Hs * Ws; ln.C = d[i - 1]; ln.outB = t; ln.ldb = d[i - 1];
-                RUN(launch_layernorm(ln, s));
+                RUN(p_ln(c, ln, s));
                 float* xn = wsalloc<float>(c, (size_t)(Hs / 2) * (Ws / 2) * d[i]);
                 GemmArgs g = conv_args(c->ds_conv[i], t, d[i - 1], Hs, Ws, 2, 0);
                 g.outF = xn; g.ldf = d[i];
-                RUN(launch_gemm(g, s));
+                RUN(p_gemm(c, g, s));
                 x = xn; Hs /= 2; Ws /= 2;
             }
             const int M = Hs * Ws, C = d[i];
@@ -445,7 +496,7 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
                 if (i == 1) { ln.outB = cat8 + c0; ln.ldb = 2 * c0; }
                 else if (i == 2) { ln.outB = cat16a + c1; ln.ldb = 2 * c1; ln.outF = feat16; ln.ldf = c1; }
                 else { ln.outB = x0b; ln.ldb = c2; }
-                RUN(launch_layernorm(ln, s));
+                RUN(p_ln(c, ln, s));
             }
         }
     }
@@ -480,8 +531,8 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
     RUN(stage_begin(c, h * 16, w * 16, s));
     const int hw = h * w, L = 2 * hw, C2 = c->cfg.dims[2];
     bf16* fb = wsalloc<bf16>(c, (size_t)L * C2);
-    RUN(launch_cast_bf16(feat_ref, C2, fb, C2, hw, C2, s));
-    RUN(launch_cast_bf16(feat_cur, C2, fb + (size_t)hw * C2, C2, hw, C2, s));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_ref, C2, fb, C2, hw, C2, s); }));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_cur, C2, fb + (size_t)hw * C2, C2, hw, C2, s); }));
     float* src = wsalloc<float>(c, (size_t)L * 256);
     bf16* srcb = wsalloc<bf16>(c, (size_t)L * 256);
     for (int l = 0; l < 2; ++l) {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5), per frame
@@ -489,27 +540,27 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
         RUN(run_conv_gn(c, c->bott, c->bott_gn, 32, 1e-5f, ACT_NONE, fb + (size_t)l * hw * C2, C2, hw, 1, 1, o, s));
     }
     bf16* qb = wsalloc<bf16>(c, (size_t)L * 256);
-    RUN(launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s); }));
     float* value = wsalloc<float>(c, (size_t)L * 256);
-    { GemmArgs g = conv_args(c->value_proj, srcb, 256, L, 1, 1, 0); g.outF = value; g.ldf = 256; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->value_proj, srcb, 256, L, 1, 1, 0); g.outF = value; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     float* offaw = wsalloc<float>(c, (size_t)L * 192);
-    { GemmArgs g = conv_args(c->offaw, qb, 256, L, 1, 1, 0); g.outF = offaw; g.ldf = 192; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->offaw, qb, 256, L, 1, 1, 0); g.outF = offaw; g.ldf = 192; RUN(p_gemm(c, g, s)); }
     bf16* attn = wsalloc<bf16>(c, (size_t)L * 256);
-    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; RUN(launch_msda_fused(m, s)); }
+    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_msda_fused(m, s); })); }
     float* y = wsalloc<float>(c, (size_t)L * 256);
-    { GemmArgs g = conv_args(c->output_proj, attn, 256, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->output_proj, attn, 256, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     {   // src = norm1(src + attn)
         LnArgs ln; ln.x = y; ln.ldx = 256; ln.gamma = c->norm1.g; ln.beta = c->norm1.b; ln.eps = 1e-5f; ln.M = L; ln.C = 256;
         ln.outF = src; ln.ldf = 256; ln.outB = srcb; ln.ldb = 256;
-        RUN(launch_layernorm(ln, s));
+        RUN(p_ln(c, ln, s));
     }
     bf16* hid = wsalloc<bf16>(c, (size_t)L * 1024);
-    { GemmArgs g = conv_args(c->lin1, srcb, 256, L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(launch_gemm(g, s)); }
-    { GemmArgs g = conv_args(c->lin2, hid, 1024, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->lin1, srcb, 256, L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(p_gemm(c, g, s)); }
+    { GemmArgs g = conv_args(c->lin2, hid, 1024, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     for (int l = 0; l < 2; ++l) {
         LnArgs ln; ln.x = y + (size_t)l * hw * 256; ln.ldx = 256; ln.gamma = c->norm2.g; ln.beta = c->norm2.b; ln.eps = 1e-5f;
         ln.M = hw; ln.C = 256; ln.outF = l ? out_cur : out_ref; ln.ldf = 256;
-        RUN(launch_layernorm(ln, s));
+        RUN(p_ln(c, ln, s));
     }
     return 0;
 }
@@ -521,10 +572,10 @@ int engine_upsample(uni_ctx* c, const float* feat, int h, int w, float* embed, h
     RUN(stage_begin(c, h * 16, w * 16, s));
     const int H = 2 * h, W = 2 * w, M = H * W;
     bf16* ps = wsalloc<bf16>(c, (size_t)M * 64);
-    RUN(launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s); }));
     bf16* mid = wsalloc<bf16>(c, (size_t)M * 256);
-    { GemmArgs g = conv_args(c->up1, ps, 64, H, W, 1, 1); g.act = ACT_RELU; g.outB = mid; g.ldb = 256; RUN(launch_gemm(g, s)); }
-    { GemmArgs g = conv_args(c->up3, mid, 256, H, W, 1, 1); g.outF = embed; g.ldf = c->cfg.embed_dim; RUN(launch_gemm(g, s)); }
+    { GemmArgs g = conv_args(c->up1, ps, 64, H, W, 1, 1); g.act = ACT_RELU; g.outB = mid; g.ldb = 256; RUN(p_gemm(c, g, s)); }
+    { GemmArgs g = conv_args(c->up3, mid, 256, H, W, 1, 1); g.outF = embed; g.ldf = c->cfg.embed_dim; RUN(p_gemm(c, g, s)); }
     return 0;
 }
 
@@ -552,7 +603,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     bf16* fb[3];
     for (int k = 0; k < 3; ++k) {
         fb[k] = wsalloc<bf16>(c, (size_t)Hk[k] * Wk[k] * ch[k]);
-        RUN(launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s); }));
     }
     int row0 = 0;
     for (int k = 0; k < 3; ++k) {
@@ -564,7 +615,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         bf16* hid = wsalloc<bf16>(c, (size_t)M * 1024);
         bf16* xb = wsalloc<bf16>(c, (size_t)M * 256);
         const int nb = (int)c->att[k].size();
-        if (nb == 0) RUN(launch_cast_bf16(x, 256, xb, 256, M, 256, s));
+        if (nb == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(x, 256, xb, 256, M, 256, s); }));
         for (int n = 0; n < nb; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nb - 1 ? xb : nullptr, s));
         bf16* tw = wsalloc<bf16>(c, (size_t)M * 512);      // [cls | reg] after the first (merged) tower conv
         { Out o; o.B = tw; o.ldb = 512; RUN(run_conv_gn(c, c->tower0[k], c->tower0_gn[k], 32, 1e-3f, ACT_SILU, xb, 256, Hk[k], Wk[k], 1, o, s)); }
@@ -580,22 +631,22 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         {   // [reg(4) | sigmoid(obj)]  (unicorn_head.py:295-304,332-334)
             GemmArgs g = conv_args(mode == 0 ? c->regobj_sot[k] : c->regobj[k], reg, ldc, M, 1, 1, 0);
             g.act = ACT_SIGMOID; g.act_col0 = 4; g.outF = ok; g.ldf = nch;
-            RUN(launch_gemm(g, s));
+            RUN(p_gemm(c, g, s));
         }
         {   // sigmoid(cls)
             GemmArgs g = conv_args(mode == 0 ? c->cls_pred_sot[k] : c->cls_pred[k], cls, ldc, M, 1, 1, 0);
             g.act = ACT_SIGMOID; g.outF = ok + 5; g.ldf = nch;
-            RUN(launch_gemm(g, s));
+            RUN(p_gemm(c, g, s));
         }
         if (cfg.mask) {   // controllers on reg_feat (ctrl_loc == "reg", unicorn_head_mask.py:333-340)
             GemmArgs g = conv_args(c->controllers[k], reg, ldc, Hk[k], Wk[k], 1, 1);
             g.outF = dyn_params + (size_t)row0 * 169; g.ldf = 169;
-            RUN(launch_gemm(g, s));
+            RUN(p_gemm(c, g, s));
         }
         row0 += M;
         c->ws_off = mark;
     }
-    RUN(launch_decode(out, out, Hk[0] * Wk[0], Wk[0], Hk[1] * Wk[1], Wk[1], Hk[2] * Wk[2], Wk[2], nch, s));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, Hk[0] * Wk[0], Wk[0], Hk[1] * Wk[1], Wk[1], Hk[2] * Wk[2], Wk[2], nch, s); }));
     if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162
         const int M8 = Hk[0] * Wk[0];
         float* xm = wsalloc<float>(c, (size_t)M8 * 128);
@@ -604,10 +655,10 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             float* r = k == 0 ? xm : wsalloc<float>(c, (size_t)M * 128);
             Out o; o.F = r; o.ldf = 128;
             RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
-            if (k > 0) RUN(launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s));
+            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s); }));
         }
         bf16* xmb = wsalloc<bf16>(c, (size_t)M8 * 128);
-        RUN(launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s); }));
         bf16* tb[2] = {wsalloc<bf16>(c, (size_t)M8 * 128), wsalloc<bf16>(c, (size_t)M8 * 128)};
         const bf16* cur = xmb;
         for (int i = 0; i < 4; ++i) {
@@ -615,19 +666,19 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             RUN(run_conv_gn(c, c->mtower[i], c->mtower_gn[i], 16, 1e-3f, ACT_RELU, cur, 128, Hk[0], Wk[0], 1, o, s));
             cur = tb[i & 1];
         }
-        { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(launch_gemm(g, s)); }
+        { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(p_gemm(c, g, s)); }
         bf16* u = tb[0] == cur ? tb[1] : tb[0];
-        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(launch_gemm(g, s)); }
-        { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(launch_gemm(g, s)); }
+        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
+        { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(p_gemm(c, g, s)); }
     }
     return 0;
 }
 
 void engine_destroy(uni_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    for (void* p : c->dev_allocs) hipFree(p);
-    if (c->ws) hipFree(c->ws);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->dev_allocs) (void)hipFree(p);
+    if (c->ws) (void)hipFree(c->ws);
     delete c;
 }

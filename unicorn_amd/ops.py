@@ -33,6 +33,8 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, a
     shp = (C.c_int64 * (2 * Ln))(*[int(v) for v in spatial_shapes.reshape(-1).tolist()])
     lsi = (C.c_int64 * Ln)(*[int(v) for v in level_start_index.reshape(-1).tolist()])
     out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
+    if out.numel() == 0:
+        return out
     L.check(L.lib().uni_msda_fwd(L.ptr(value), shp, lsi, L.ptr(loc), L.ptr(attn), L.ptr(out), N, S, M, D, Lq, Ln, P,
                                  L.stream_ptr()), "uni_msda_fwd")
     return out
