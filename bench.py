@@ -171,6 +171,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
+        cores = min(cores, 16)
         torch.set_num_threads(cores)
         cf, cbox = synth.synth_clip(H, W, 1 + args.cpu_frames, seed=1)
         with torch.no_grad():

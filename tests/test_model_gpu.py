@@ -133,7 +133,7 @@ def _vs_oracle(exp, H, W, tag):
     m, cfg, P = build(exp)
     frames, box = synth.synth_clip(H, W, 2, seed=1)
     r = hip_sot_step(m, cfg, frames, box)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box has 100s of cores; torch CPU ops scale badly past ~16
     with torch.no_grad():
         st = uo.sot_init(P, cfg, frames[0], box)
         o = uo.sot_step(P, cfg, st, frames[1])

@@ -1,80 +1,54 @@
-// K1b / K2 / K5: bf16 MFMA implicit-GEMM for every dense contraction of the path
+// K1b / K2 / K5: 16-bit MFMA implicit-GEMM for every dense contraction of the path
 // (ConvNeXt pointwise MLPs, PAFPN/head 1x1 and 3x3 convs, 2x2/s2 downsample, transformer Linears).
 //
 //   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )        m = output pixel, n = out channel
 //
-// A is an NHWC bf16 activation map; for CONV the k index is (ky,kx,c) and the A tile is gathered
-// on the fly with zero padding (implicit GEMM, nothing is materialised). W is pre-packed
-// [Npad][Kpad] bf16 (K contiguous, zero padded).  fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+// A is an NHWC bf16 activation map; for CONV the k index is (ky,kx,c) and the A tile is gathered on the
+// fly with zero padding (implicit GEMM, nothing is materialised).  W is pre-packed [Npad][Kpad] bf16
+// (K contiguous, zero padded).  fp32 accumulation on v_mfma_f32_32x32x16_bf16.
 //
-// Geometry: 256 threads = 4 waves (2x2), wave tile = (32*TM) x (32*TN), block tile BM x BN =
-// (64*TM) x (64*TN), BK = 64.  Register-staged global->LDS (needed for the zero-padded gather),
-// two LDS buffers, one barrier per K step.  LDS rows are 128 B; 16-B chunks are XOR-swizzled with
-// ((row>>1)&7) so that the ds_read_b128 fragment reads of any 16-lane group hit 16 distinct
-// (row-parity, chunk) bank slots (MI355X LDS: 64 banks x 4 B, b128 groups of 16 lanes).
-// Blocks are remapped so each XCD (private L2) owns a contiguous range of M panels.
+// CDNA4 design notes
+//  * 256 threads = 4 waves (2x2); wave tile (32*TM pixels) x (32*TN channels); block tile BM x BN =
+//    (64*TM) x (64*TN); BK = 64.
+//  * global -> LDS goes through the LDS-DMA path (global_load_lds_dwordx4, 1 KiB per wave instruction, no
+//    VGPR round trip), two LDS buffers, ONE barrier per K step: the loads of tile k+1 are in flight while
+//    tile k is multiplied.  The DMA writes lane-linear (base + lane*16 B), so the bank-conflict XOR swizzle
+//    chunk' = chunk ^ ((row>>1)&7) is applied on the per-lane SOURCE address and again on the ds_read_b128
+//    fragment reads (both-sides-or-neither).  Out-of-image / K-tail lanes read a 16-byte zero page.
+//  * The MFMA is issued "swapped": weights are the A operand, pixels the B operand, so every lane ends up
+//    with 4 CONSECUTIVE output channels of one pixel per accumulator quad.  The epilogue is therefore fully
+//    vectorised (float4 bias / residual / fp32 stores) and bf16 outputs are widened to 16-byte stores with
+//    v_permlane32_swap (store-issue count, not bandwidth, bounds small-K GEMMs on this chip).
+//  * GroupNorm statistics of the raw conv output are reduced in the epilogue (reduce-scatter butterfly over
+//    the 32 pixel lanes -> LDS -> one double atomic per group per block).
+//  * Blocks are remapped so each XCD (private 4 MiB L2) owns a contiguous range of M panels.
 #include "kernels.h"
 
-template <int A_CH, int B_CH, bool CONV>
-__device__ __forceinline__ void gemm_load_tiles(const GemmArgs& p, int kt, int kc, const int (&a_pix)[A_CH],
-                                                const bf16* wbase, u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH]) {
-    const int k = kt * 64 + kc * 8;
-    const bool kok = k < p.K;
-    if (CONV) {
-        int tap = k / p.Cin;
-        int c = k - tap * p.Cin;
-        int ky = tap / p.KW, kx = tap - ky * p.KW;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            int oy = a_pix[i] >> 16, ox = a_pix[i] & 0xffff;
-            int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-            bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-            const bf16* src = p.A + ((size_t)(iy * p.Win + ix) * p.lda + c);
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(src);
-            ra[i] = v;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const bf16* src = p.A + ((size_t)a_pix[i] * p.lda + k);
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (kok) v = *reinterpret_cast<const u32x4*>(src);
-            ra[i] = v;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i)
-        rb[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)i * 32 * p.Kpad + kt * 64);
-}
+__device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
 
-template <int A_CH, int B_CH>
-__device__ __forceinline__ void gemm_store_tiles(bf16* a, bf16* b, int lrow, int kc, const u32x4 (&ra)[A_CH],
-                                                 const u32x4 (&rb)[B_CH]) {
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        int row = lrow + i * 32;
-        *reinterpret_cast<u32x4*>(a + row * 64 + ((kc ^ ((row >> 1) & 7)) << 3)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-        int row = lrow + i * 32;
-        *reinterpret_cast<u32x4*>(b + row * 64 + ((kc ^ ((row >> 1) & 7)) << 3)) = rb[i];
-    }
-}
+#define GLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+#define OPAQUE64(x)                                      \
+    do {                                                 \
+        int _lo = (int)(x), _hi = (int)((x) >> 32);      \
+        asm volatile("" : "+v"(_lo), "+v"(_hi));         \
+        (x) = ((long)_hi << 32) | (unsigned)_lo;         \
+    } while (0)
 
 template <int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 64;
-    constexpr int A_CH = BM / 32;   // 16-B chunks per thread for the A tile
-    constexpr int B_CH = BN / 32;
+    constexpr int A_PC = BM / 32;   // 1-KiB pieces (8 rows x 128 B) per wave for the A tile
+    constexpr int B_PC = BN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*BK]
     bf16* Bs = As + 2 * BM * BK;                              // [2][BN*BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- XCD-aware bijective block remap (block b runs on XCD b%8) ----
@@ -88,13 +62,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int bm = L / nbn, bn = L % nbn;
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // ---- per-thread load descriptors ----
-    const int kc = tid & 7;            // 16-B chunk within the 64-wide K slab
-    const int lrow = tid >> 3;         // 0..31
-    int a_pix[A_CH];                   // non-conv: element offset of row start; conv: packed (oy<<16|ox)
+    // ---- per-lane DMA source descriptors ----
+    // piece pc = wave + 4*i covers tile rows 8*pc .. 8*pc+7; lane -> row 8*pc + (lane>>3), physical chunk lane&7.
+    // logical chunk = physical ^ ((row>>1)&7) = (lane&7) ^ ((4*wave + (lane>>4)) & 7)   (independent of i)
+    const int lrow = lane >> 3;
+    const int lch = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    const char* abase = reinterpret_cast<const char*>(p.A);
+    const long zoff = reinterpret_cast<const char*>(&g_zero_page) - abase;
+    int a_pix[A_PC];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        int m = m0 + lrow + i * 32;
+    for (int i = 0; i < A_PC; ++i) {
+        int m = m0 + 8 * (wave + 4 * i) + lrow;
         m = m < p.M ? m : p.M - 1;
         if (CONV) {
             int oy = m / p.Wout, ox = m - oy * p.Wout;
@@ -103,9 +81,38 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             a_pix[i] = m;
         }
     }
-    const bf16* wbase = p.W + (size_t)(n0 + lrow) * p.Kpad + kc * 8;
+    const bf16* wbase = p.W + (size_t)(n0 + 8 * wave + lrow) * p.Kpad + lch * 8;
 
-    u32x4 ra[A_CH], rb[B_CH];
+    auto issue = [&](int kt, int buf) {
+        const int k = kt * BK + lch * 8;
+        const bool kok = k < p.K;
+        char* adst = reinterpret_cast<char*>(As + buf * BM * BK) + wave * 1024;
+        char* bdst = reinterpret_cast<char*>(Bs + buf * BN * BK) + wave * 1024;
+        if (CONV) {
+            int tap = k / p.Cin;
+            int c = k - tap * p.Cin;
+            int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+            for (int i = 0; i < A_PC; ++i) {
+                int oy = a_pix[i] >> 16, ox = a_pix[i] & 0xffff;
+                int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                long off = ok ? (long)(((size_t)(iy * p.Win + ix) * p.lda + c) * sizeof(bf16)) : zoff;
+                OPAQUE64(off);   // keep ONE DMA per piece (hipcc otherwise splits the select into exec-masked branches)
+                GLDS16(abase + off, adst + i * 4096);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PC; ++i) {
+                long off = kok ? (long)(((size_t)a_pix[i] * p.lda + k) * sizeof(bf16)) : zoff;
+                OPAQUE64(off);
+                GLDS16(abase + off, adst + i * 4096);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PC; ++i) GLDS16(wbase + (size_t)i * 32 * p.Kpad + kt * BK, bdst + i * 4096);
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -115,15 +122,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.Kpad / BK;
-    gemm_load_tiles<A_CH, B_CH, CONV>(p, 0, kc, a_pix, wbase, ra, rb);
-    gemm_store_tiles<A_CH, B_CH>(As, Bs, lrow, kc, ra, rb);
-    __syncthreads();
-
-    const int fr = lane & 31;          // fragment row (A) / col (B)
+    const int fr = lane & 31;          // fragment row within a 32-row sub-tile
     const int fh = lane >> 5;          // which 8-wide half of the 16-deep MFMA K step
+    issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gemm_load_tiles<A_CH, B_CH, CONV>(p, kt + 1, kc, a_pix, wbase, ra, rb);
+        __syncthreads();               // tile kt landed (vmcnt(0) + barrier); everyone is done with buf^1
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
         const bf16* a = As + buf * BM * BK;
         const bf16* b = Bs + buf * BN * BK;
 #pragma unroll
@@ -143,55 +148,159 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)   // swapped: D[n][m], lane -> pixel m = lane&31, channels 4*fh + (r&3) + 8*(r>>2)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) gemm_store_tiles<A_CH, B_CH>(As + (buf ^ 1) * BM * BK, Bs + (buf ^ 1) * BN * BK, lrow, kc, ra, rb);
-        __syncthreads();
     }
 
-    // ---- epilogue ----
-    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float gsum[TN], gsq[TN];
+    // ---- epilogue: lane owns pixel row = .. + fr and, per quad g, channels col0 + 8g + 4fh + {0,1,2,3} ----
+    float gs[TN][16], gq[TN][16];
+    if (p.stats) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { gsum[j] = 0.f; gsq[j] = 0.f; }
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * 32 * TN + j * 32 + fr;
-        const bool cok = col < p.N;
-        const float bias = (p.bias && cok) ? p.bias[col] : 0.f;
-        const int act = (col >= p.act_col0) ? p.act : ACT_NONE;
+            for (int r = 0; r < 16; ++r) { gs[j][r] = 0.f; gq[j][r] = 0.f; }
+    }
+    const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * 32 * TM + i * 32 + fr;
+        const bool rok = row < p.M;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < p.M && cok) {
-                    float v = acc[i][j][r] + bias;
-                    gsum[j] += v;
-                    gsq[j] += v * v;
-                    v = act_apply(v, act);
-                    if (p.res) v += p.res[(size_t)row * p.ldr + col];
-                    if (p.outF) p.outF[(size_t)row * p.ldf + col] = v;
-                    if (p.outB) p.outB[(size_t)row * p.ldb + col] = (bf16)v;
+        for (int j = 0; j < TN; ++j) {
+            const int cbase = n0 + wn * 32 * TN + j * 32 + 4 * fh;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = cbase + 8 * g;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (col + e < p.N) ? p.bias[col + e] : 0.f;
+                }
+                if (p.stats && rok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gs[j][4 * g + e] += v[e]; gq[j][4 * g + e] += v[e] * v[e]; }
+                }
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (col + e >= p.act_col0) ? act_apply(v[e], p.act) : v[e];
+                }
+                const bool full = vec_ok && col + 3 < p.N;
+                if (p.res && rok) {
+                    const float* rp = p.res + (size_t)row * p.ldr + col;
+                    if (full && (p.ldr & 3) == 0) {
+                        f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += rp[e];
+                    }
+                }
+                if (p.outF && rok) {
+                    float* op = p.outF + (size_t)row * p.ldf + col;
+                    if (full && (p.ldf & 3) == 0) {
+                        f32x4 o4 = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(op) = o4;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < p.N) op[e] = v[e];
+                    }
+                }
+                if (p.outB) {
+                    bf16x2 lo = {(bf16)v[0], (bf16)v[1]}, hi = {(bf16)v[2], (bf16)v[3]};
+                    pk[g][0] = __builtin_bit_cast(unsigned, lo);
+                    pk[g][1] = __builtin_bit_cast(unsigned, hi);
+                }
+            }
+            if (p.outB) {
+                // widen to 16-B stores: after the half-swap lanes <32 hold channels 8g..8g+7 of quad pair (g,g+1),
+                // lanes >=32 hold channels 8(g+1)..8(g+1)+7
+                const int cb0 = n0 + wn * 32 * TN + j * 32;
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    const int col = cb0 + 8 * (g + fh);
+                    if (rok) {
+                        bf16* op = p.outB + (size_t)row * p.ldb + col;
+                        if ((p.ldb & 7) == 0 && col + 7 < p.N && ((reinterpret_cast<uintptr_t>(p.outB) & 15) == 0)) {
+                            u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+                            *reinterpret_cast<u32x4*>(op) = o4;
+                        } else {
+                            unsigned w4[4] = {s0[0], s1[0], s0[1], s1[1]};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (col + e < p.N) {
+                                    unsigned short h = (unsigned short)(w4[e >> 1] >> (16 * (e & 1)));
+                                    reinterpret_cast<unsigned short*>(op)[e] = h;
+                                }
+                        }
+                    }
                 }
             }
         }
     }
     if (p.stats) {
-        // per-column partial sums -> per-GroupNorm-group sums -> one double atomic per group per block
+        // reduce over the 32 pixel lanes with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps
+        // register index r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
         float* red = reinterpret_cast<float*>(smem);          // [2 wm][BN][2]
         float* gacc = red + 2 * BN * 2;                       // [64][2]
         __syncthreads();
         if (tid < 128) gacc[tid] = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float s = gsum[j] + __shfl_xor(gsum[j], 32, 64);
-            float q = gsq[j] + __shfl_xor(gsq[j], 32, 64);
-            if (fh == 0) {
-                int c = wn * 32 * TN + j * 32 + fr;
-                red[(wm * BN + c) * 2 + 0] = s;
-                red[(wm * BN + c) * 2 + 1] = q;
+            float s8[8], q8[8];
+            {
+                const bool up = (lane >> 4) & 1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float ss = up ? gs[j][r] : gs[j][r + 8], sq = up ? gq[j][r] : gq[j][r + 8];
+                    float ks = up ? gs[j][r + 8] : gs[j][r], kq = up ? gq[j][r + 8] : gq[j][r];
+                    s8[r] = ks + __shfl_xor(ss, 16, 64);
+                    q8[r] = kq + __shfl_xor(sq, 16, 64);
+                }
+            }
+            float s4[4], q4[4];
+            {
+                const bool up = (lane >> 3) & 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
+                    float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
+                    s4[r] = ks + __shfl_xor(ss, 8, 64);
+                    q4[r] = kq + __shfl_xor(sq, 8, 64);
+                }
+            }
+            float s2[2], q2[2];
+            {
+                const bool up = (lane >> 2) & 1;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
+                    float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
+                    s2[r] = ks + __shfl_xor(ss, 4, 64);
+                    q2[r] = kq + __shfl_xor(sq, 4, 64);
+                }
+            }
+            float s1, q1;
+            {
+                const bool up = (lane >> 1) & 1;
+                float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
+                float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
+                s1 = ks + __shfl_xor(ss, 2, 64);
+                q1 = kq + __shfl_xor(sq, 2, 64);
+            }
+            s1 += __shfl_xor(s1, 1, 64);
+            q1 += __shfl_xor(q1, 1, 64);
+            if ((lane & 1) == 0) {
+                const int r = (lane >> 1) & 15;
+                const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = q1;
             }
         }
         __syncthreads();
@@ -222,19 +331,20 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     UNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     UNI_REQUIRE(a.K % 8 == 0 && a.Kpad % 64 == 0 && a.Kpad >= a.K, "gemm: K=%d Kpad=%d", a.K, a.Kpad);
-    UNI_REQUIRE(a.lda % 8 == 0, "gemm: lda=%d must be a multiple of 8", a.lda);
+    UNI_REQUIRE(a.lda % 8 == 0 && ((uintptr_t)a.A & 15) == 0, "gemm: lda=%d / A must be 16-byte aligned", a.lda);
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
-    if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin, "gemm: conv K mismatch");
+    if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 65536, "gemm: conv K mismatch");
     if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
-    // tile choice: fill >= ~2 waves of blocks on 256 CUs, prefer the big tile (Npad is a multiple of 128)
+    // tile choice (measured on MI355X, tools/gemm_bench.py): plain GEMMs want >= ~400 blocks of 128x64, implicit
+    // convs amortise their gather address math over wider-N tiles
     const long b22 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    const long b21 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
     const long b12 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
     int cfg = a.force_cfg;
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
-        else if (b22 >= 384) cfg = 22;
-        else if (b12 >= 256) cfg = 12;
-        else cfg = 11;
+        else if (conv) cfg = b22 >= 400 ? 22 : (b12 >= 400 ? 12 : 11);
+        else cfg = b22 >= 2048 ? 22 : (b21 >= 400 ? 21 : 11);
     }
 #define GO(TM, TN) return conv ? launch_cfg<TM, TN, true>(a, s) : launch_cfg<TM, TN, false>(a, s)
     switch (cfg) {
