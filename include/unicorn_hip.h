@@ -56,6 +56,7 @@ typedef struct uni_model_cfg {
     int32_t embed_dim;   /* 128 */
     int32_t up_rate;     /* 8 // d_rate (4) */
     int32_t d_rate;      /* 2 */
+    int32_t precision;   /* 0 = bf16 MFMA operands / fp32 accumulate (default); 1 = exact fp32 (v_mfma_f32_32x32x2_f32) */
 } uni_model_cfg;
 
 const char* uni_last_error(void);

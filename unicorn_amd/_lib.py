@@ -11,7 +11,8 @@ c_i = C.c_int
 
 class ModelCfg(C.Structure):
     _fields_ = [("dims", C.c_int32 * 4), ("depths", C.c_int32 * 4), ("num_classes", C.c_int32), ("mask", C.c_int32),
-                ("n_layer_att", C.c_int32), ("embed_dim", C.c_int32), ("up_rate", C.c_int32), ("d_rate", C.c_int32)]
+                ("n_layer_att", C.c_int32), ("embed_dim", C.c_int32), ("up_rate", C.c_int32), ("d_rate", C.c_int32),
+                ("precision", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/unicorn_hip.h

@@ -34,10 +34,12 @@ uni_ctx* uni_ctx_create(int device_id, const uni_model_cfg* cfg) {
     }
     for (int i = 0; i < 4; ++i)
         if (cfg->dims[i] <= 0 || cfg->dims[i] % 8 || cfg->depths[i] < 0) { uni_set_error("bad cfg dims/depths"); return nullptr; }
+    if (cfg->precision != 0 && cfg->precision != 1) { uni_set_error("precision %d unknown (0 = bf16, 1 = fp32)", cfg->precision); return nullptr; }
     if (cfg->embed_dim != 128) { uni_set_error("embed_dim %d unsupported (128)", cfg->embed_dim); return nullptr; }
     uni_ctx* c = new uni_ctx();
     c->device = device_id;
     c->cfg = *cfg;
+    c->b32 = cfg->precision == 1;
     return c;
 }
 void uni_ctx_destroy(uni_ctx* ctx) { engine_destroy(ctx); }

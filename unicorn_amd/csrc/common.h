@@ -36,6 +36,35 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// "act" buffers hold GEMM operands: bf16 (es=2) in the default precision, fp32 (es=4) in the exact-fp32 mode.
+// idx is in ELEMENTS; b32 is wave-uniform.
+__device__ __forceinline__ void act_store4(void* base, size_t idx, float a, float b, float c, float d, int b32) {
+    if (b32) {
+        f32x4 o = {a, b, c, d};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = o;
+    } else {
+        bf16x4 o = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + idx) = o;
+    }
+}
+__device__ __forceinline__ void act_store8(void* base, size_t idx, const float (&v)[8], int b32) {
+    if (b32) {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        float* p = reinterpret_cast<float*>(base) + idx;
+        *reinterpret_cast<f32x4*>(p) = o0;
+        *reinterpret_cast<f32x4*>(p + 4) = o1;
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + idx) = o;
+    }
+}
+__device__ __forceinline__ void act_store1(void* base, size_t idx, float a, int b32) {
+    if (b32) reinterpret_cast<float*>(base)[idx] = a;
+    else reinterpret_cast<bf16*>(base)[idx] = (bf16)a;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // error plumbing (api.cpp owns the storage)

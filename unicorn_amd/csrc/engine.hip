@@ -103,7 +103,27 @@ static PConv pack_convs(uni_ctx* c, const std::vector<ConvSrc>& srcs, int Cin, i
         }
         n0 += s.N;
     }
-    p.W = reinterpret_cast<bf16*>(dev_upload<uint16_t>(c, packed.data(), packed.size()));
+    p.b32 = c->b32;
+    if (c->b32) {   // exact-fp32 mode: same [Npad][Kpad] (ky,kx,c) layout, fp32 elements
+        std::vector<float> pf((size_t)Npad * p.Kpad, 0.f);
+        int r0 = 0;
+        for (auto& s : srcs) {
+            const float* w = host_param(c, s.w, (size_t)s.N * p.K);
+            if (w)
+                for (int n = 0; n < s.N; ++n) {
+                    const float sc = s.row_scale ? s.row_scale[n] : 1.f;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int ky = 0; ky < KH; ++ky)
+                            for (int kx = 0; kx < KW; ++kx)
+                                pf[(size_t)(r0 + n) * p.Kpad + (ky * KW + kx) * Cin + ci] = sc * w[(size_t)n * p.K + (ci * KH + ky) * KW + kx];
+                }
+            r0 += s.N;
+        }
+        c->missing.resize(c->missing.size());   // (host_param already recorded misses above)
+        p.W = reinterpret_cast<bf16*>(dev_upload<float>(c, pf.data(), pf.size()));
+    } else {
+        p.W = reinterpret_cast<bf16*>(dev_upload<uint16_t>(c, packed.data(), packed.size()));
+    }
     p.bias = any_bias ? dev_upload<float>(c, bias.data(), N) : nullptr;
     return p;
 }
@@ -333,14 +353,17 @@ static int prof_run(uni_ctx* c, int cls, double work, hipStream_t s, F&& f) {
 static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
     return prof_run(c, PC_GEMM, 2.0 * g.M * g.N * g.K, s, [&] { return launch_gemm(g, s); });
 }
-static int p_dwln(uni_ctx* c, const DwLnArgs& d, hipStream_t s) {
+static int p_dwln(uni_ctx* c, DwLnArgs d, hipStream_t s) {
+    d.b32 = c->b32;
     return prof_run(c, PC_DWLN, (double)d.H * d.W * d.C * 6.0 + 49.0 * d.C * 4, s, [&] { return launch_dwconv7_ln(d, s); });
 }
-static int p_gn(uni_ctx* c, const GnApplyArgs& a, hipStream_t s) {
+static int p_gn(uni_ctx* c, GnApplyArgs a, hipStream_t s) {
+    a.b32 = c->b32;
     double b = (double)a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0) + (a.outUp ? 8 : 0));
     return prof_run(c, PC_GN, b, s, [&] { return launch_gn_apply(a, s); });
 }
-static int p_ln(uni_ctx* c, const LnArgs& a, hipStream_t s) {
+static int p_ln(uni_ctx* c, LnArgs a, hipStream_t s) {
+    a.b32 = c->b32;
     double b = (double)a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0));
     return prof_run(c, PC_LN, b, s, [&] { return launch_layernorm(a, s); });
 }
@@ -367,25 +390,37 @@ int engine_prof_end(uni_ctx* c, double* out) {   // out[PC_NCLS][3] = {ms, work,
 // ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------
+// activation (GEMM-operand) buffer pointer: bf16 elements by default, fp32 in the exact-fp32 precision mode
+struct ActPtr {
+    char* p = nullptr; int es = 2;
+    ActPtr() {}
+    ActPtr(char* p_, int es_) : p(p_), es(es_) {}
+    ActPtr operator+(size_t elems) const { return ActPtr(p + elems * es, es); }
+    operator bf16*() const { return reinterpret_cast<bf16*>(p); }
+    bool operator==(const ActPtr& o) const { return p == o.p; }
+};
+static ActPtr actalloc(uni_ctx* c, size_t n) { return ActPtr(wsalloc<char>(c, n * (c->b32 ? 4 : 2)), c->b32 ? 4 : 2); }
+
 struct Out {
     float* F = nullptr; int ldf = 0;
-    bf16* B = nullptr; int ldb = 0;
-    bf16* Up = nullptr; int ldu = 0;
+    ActPtr B; int ldb = 0;
+    ActPtr Up; int ldu = 0;
     const float* prior = nullptr; const float* pbeta = nullptr;
 };
 
-static GemmArgs conv_args(const PConv& p, const bf16* A, int lda, int Hin, int Win, int stride, int pad) {
+static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, int stride, int pad) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = p.W;
     const int Hout = (Hin + 2 * pad - p.KH) / stride + 1, Wout = (Win + 2 * pad - p.KW) / stride + 1;
     g.M = Hout * Wout; g.N = p.N; g.K = p.K; g.Kpad = p.Kpad;
     g.Hin = Hin; g.Win = Win; g.Cin = p.Cin; g.KH = p.KH; g.KW = p.KW; g.stride = stride; g.pad = pad; g.Wout = Wout;
     g.bias = p.bias;
+    g.b32 = p.b32;
     return g;
 }
 
 // conv (no act) -> GroupNorm(G) -> act, written to `o`
-static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, float eps, int act, const bf16* A, int lda,
+static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, float eps, int act, ActPtr A, int lda,
                        int Hin, int Win, int stride, const Out& o, hipStream_t s) {
     const size_t mark = c->ws_off;
     GemmArgs g = conv_args(conv, A, lda, Hin, Win, stride, (conv.KH - 1) / 2);
@@ -403,12 +438,12 @@ static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, 
     c->ws_off = mark;     // raw is dead once gn_apply is enqueued (single in-order stream)
     return 0;
 }
-static int run_baseconv(uni_ctx* c, const PBaseConv& b, const bf16* A, int lda, int Hin, int Win, const Out& o, hipStream_t s) {
+static int run_baseconv(uni_ctx* c, const PBaseConv& b, ActPtr A, int lda, int Hin, int Win, const Out& o, hipStream_t s) {
     return run_conv_gn(c, b.conv, b.gn, 16, 1e-3f, ACT_SILU, A, lda, Hin, Win, b.stride, o, s);
 }
 
 // ConvNeXt block on the fp32 residual stream x [H*W][C] (in place); t/hid are caller-provided scratch
-static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, bf16* t, bf16* hid, bf16* outB, hipStream_t s) {
+static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr t, ActPtr hid, ActPtr outB, hipStream_t s) {
     const int C = b.C, M = H * W;
     DwLnArgs d;
     d.x = x; d.w = b.dw_w; d.bias = b.dw_b; d.gamma = b.ln.g; d.beta = b.ln.b; d.eps = 1e-6f;
@@ -424,15 +459,15 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, bf16* 
 }
 
 // CSP layer: cat buffer `in` [M][cin] bf16 -> `o`
-static int run_csp(uni_ctx* c, const PCsp& p, const bf16* in, int H, int W, const Out& o, hipStream_t s) {
+static int run_csp(uni_ctx* c, const PCsp& p, ActPtr in, int H, int W, const Out& o, hipStream_t s) {
     const int M = H * W, h = p.h;
     const size_t mark = c->ws_off;
-    bf16* cat = wsalloc<bf16>(c, (size_t)M * 2 * h);     // [x_1 | x_2]
-    bf16* t1 = wsalloc<bf16>(c, (size_t)M * h);
-    bf16* t2 = wsalloc<bf16>(c, (size_t)M * h);
+    ActPtr cat = actalloc(c, (size_t)M * 2 * h);     // [x_1 | x_2]
+    ActPtr t1 = actalloc(c, (size_t)M * h);
+    ActPtr t2 = actalloc(c, (size_t)M * h);
     Out o12; o12.B = cat; o12.ldb = 2 * h;
     RUN(run_conv_gn(c, p.c12, p.gn12, 32, 1e-3f, ACT_SILU, in, p.cin, H, W, 1, o12, s));
-    const bf16* cur = cat; int ld = 2 * h;
+    ActPtr cur = cat; int ld = 2 * h;
     for (int i = 0; i < 3; ++i) {
         Out a; a.B = t1; a.ldb = h;
         RUN(run_baseconv(c, p.m1[i], cur, ld, H, W, a, s));
@@ -458,11 +493,11 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
     const int H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
     const int M8 = H8 * W8, M16 = H16 * W16, M32 = H32 * W32;
     // persistent (for this call) PAFPN inputs
-    bf16* cat8 = wsalloc<bf16>(c, (size_t)M8 * 2 * c0);      // [up(fpn_out1) | x2]
-    bf16* cat16a = wsalloc<bf16>(c, (size_t)M16 * 2 * c1);   // [up(fpn_out0) | x1]
-    bf16* cat16b = wsalloc<bf16>(c, (size_t)M16 * 2 * c0);   // [p_out1 | fpn_out1]
-    bf16* cat32 = wsalloc<bf16>(c, (size_t)M32 * 2 * c1);    // [p_out0 | fpn_out0]
-    bf16* x0b = wsalloc<bf16>(c, (size_t)M32 * c2);
+    ActPtr cat8 = actalloc(c, (size_t)M8 * 2 * c0);      // [up(fpn_out1) | x2]
+    ActPtr cat16a = actalloc(c, (size_t)M16 * 2 * c1);   // [up(fpn_out0) | x1]
+    ActPtr cat16b = actalloc(c, (size_t)M16 * 2 * c0);   // [p_out1 | fpn_out1]
+    ActPtr cat32 = actalloc(c, (size_t)M32 * 2 * c1);    // [p_out0 | fpn_out0]
+    ActPtr x0b = actalloc(c, (size_t)M32 * c2);
     // ---- ConvNeXt ----
     {
         int Hs = H / 4, Ws = W / 4;
@@ -474,7 +509,7 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
         for (int i = 0; i < 4; ++i) {
             if (i > 0) {
                 // LN_cf + conv2x2/s2 (convnext.py:80-86)
-                bf16* t = wsalloc<bf16>(c, (size_t)Hs * Ws * d[i - 1]);
+                ActPtr t = actalloc(c, (size_t)Hs * Ws * d[i - 1]);
                 LnArgs ln;
                 ln.x = x; ln.ldx = d[i - 1]; ln.gamma = c->ds_ln[i].g; ln.beta = c->ds_ln[i].b; ln.eps = 1e-6f;
                 ln.M = Hs * Ws; ln.C = d[i - 1]; ln.outB = t; ln.ldb = d[i - 1];
@@ -486,9 +521,9 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
                 x = xn; Hs /= 2; Ws /= 2;
             }
             const int M = Hs * Ws, C = d[i];
-            bf16* t = wsalloc<bf16>(c, (size_t)M * C);
-            bf16* hid = wsalloc<bf16>(c, (size_t)M * 4 * C);
-            for (auto& b : c->blocks[i]) RUN(run_block(c, b, x, Hs, Ws, t, hid, nullptr, s));
+            ActPtr t = actalloc(c, (size_t)M * C);
+            ActPtr hid = actalloc(c, (size_t)M * 4 * C);
+            for (auto& b : c->blocks[i]) RUN(run_block(c, b, x, Hs, Ws, t, hid, ActPtr(), s));
             if (i >= 1) {
                 LnArgs ln;
                 ln.x = x; ln.ldx = C; ln.gamma = c->out_norm[i].g; ln.beta = c->out_norm[i].b; ln.eps = 1e-6f;
@@ -506,17 +541,17 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
         o.B = cat32 + c1; o.ldb = 2 * c1; o.Up = cat16a; o.ldu = 2 * c1;
         RUN(run_baseconv(c, c->lateral0, x0b, c2, H32, W32, o, s));
     }
-    bf16* f_out0 = wsalloc<bf16>(c, (size_t)M16 * c1);
+    ActPtr f_out0 = actalloc(c, (size_t)M16 * c1);
     { Out o; o.B = f_out0; o.ldb = c1; RUN(run_csp(c, c->c3p4, cat16a, H16, W16, o, s)); }
     {
         Out o;  // fpn_out1 -> cat16b[:, c0:] and upsampled into cat8[:, :c0]
         o.B = cat16b + c0; o.ldb = 2 * c0; o.Up = cat8; o.ldu = 2 * c0;
         RUN(run_baseconv(c, c->reduce1, f_out0, c1, H16, W16, o, s));
     }
-    bf16* pan2b = wsalloc<bf16>(c, (size_t)M8 * c0);
+    ActPtr pan2b = actalloc(c, (size_t)M8 * c0);
     { Out o; o.F = fpn0; o.ldf = c0; o.B = pan2b; o.ldb = c0; RUN(run_csp(c, c->c3p3, cat8, H8, W8, o, s)); }
     { Out o; o.B = cat16b; o.ldb = 2 * c0; RUN(run_baseconv(c, c->bu2, pan2b, c0, H8, W8, o, s)); }
-    bf16* pan1b = wsalloc<bf16>(c, (size_t)M16 * c1);
+    ActPtr pan1b = actalloc(c, (size_t)M16 * c1);
     { Out o; o.F = fpn1; o.ldf = c1; o.B = pan1b; o.ldb = c1; RUN(run_csp(c, c->c3n3, cat16b, H16, W16, o, s)); }
     { Out o; o.B = cat32; o.ldb = 2 * c1; RUN(run_baseconv(c, c->bu1, pan1b, c1, H16, W16, o, s)); }
     { Out o; o.F = fpn2; o.ldf = c2; RUN(run_csp(c, c->c3n4, cat32, H32, W32, o, s)); }
@@ -530,23 +565,23 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
                        int h, int w, float* out_ref, float* out_cur, hipStream_t s) {
     RUN(stage_begin(c, h * 16, w * 16, s));
     const int hw = h * w, L = 2 * hw, C2 = c->cfg.dims[2];
-    bf16* fb = wsalloc<bf16>(c, (size_t)L * C2);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_ref, C2, fb, C2, hw, C2, s); }));
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_cur, C2, fb + (size_t)hw * C2, C2, hw, C2, s); }));
+    ActPtr fb = actalloc(c, (size_t)L * C2);
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_ref, C2, fb, C2, hw, C2, s, c->b32); }));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_cur, C2, fb + (size_t)hw * C2, C2, hw, C2, s, c->b32); }));
     float* src = wsalloc<float>(c, (size_t)L * 256);
-    bf16* srcb = wsalloc<bf16>(c, (size_t)L * 256);
+    ActPtr srcb = actalloc(c, (size_t)L * 256);
     for (int l = 0; l < 2; ++l) {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5), per frame
         Out o; o.F = src + (size_t)l * hw * 256; o.ldf = 256; o.B = srcb + (size_t)l * hw * 256; o.ldb = 256;
         RUN(run_conv_gn(c, c->bott, c->bott_gn, 32, 1e-5f, ACT_NONE, fb + (size_t)l * hw * C2, C2, hw, 1, 1, o, s));
     }
-    bf16* qb = wsalloc<bf16>(c, (size_t)L * 256);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s); }));
+    ActPtr qb = actalloc(c, (size_t)L * 256);
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s, c->b32); }));
     float* value = wsalloc<float>(c, (size_t)L * 256);
     { GemmArgs g = conv_args(c->value_proj, srcb, 256, L, 1, 1, 0); g.outF = value; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     float* offaw = wsalloc<float>(c, (size_t)L * 192);
     { GemmArgs g = conv_args(c->offaw, qb, 256, L, 1, 1, 0); g.outF = offaw; g.ldf = 192; RUN(p_gemm(c, g, s)); }
-    bf16* attn = wsalloc<bf16>(c, (size_t)L * 256);
-    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_msda_fused(m, s); })); }
+    ActPtr attn = actalloc(c, (size_t)L * 256);
+    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; m.b32 = c->b32; RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_msda_fused(m, s); })); }
     float* y = wsalloc<float>(c, (size_t)L * 256);
     { GemmArgs g = conv_args(c->output_proj, attn, 256, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     {   // src = norm1(src + attn)
@@ -554,7 +589,7 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
         ln.outF = src; ln.ldf = 256; ln.outB = srcb; ln.ldb = 256;
         RUN(p_ln(c, ln, s));
     }
-    bf16* hid = wsalloc<bf16>(c, (size_t)L * 1024);
+    ActPtr hid = actalloc(c, (size_t)L * 1024);
     { GemmArgs g = conv_args(c->lin1, srcb, 256, L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(p_gemm(c, g, s)); }
     { GemmArgs g = conv_args(c->lin2, hid, 1024, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     for (int l = 0; l < 2; ++l) {
@@ -571,9 +606,9 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
 int engine_upsample(uni_ctx* c, const float* feat, int h, int w, float* embed, hipStream_t s) {
     RUN(stage_begin(c, h * 16, w * 16, s));
     const int H = 2 * h, W = 2 * w, M = H * W;
-    bf16* ps = wsalloc<bf16>(c, (size_t)M * 64);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s); }));
-    bf16* mid = wsalloc<bf16>(c, (size_t)M * 256);
+    ActPtr ps = actalloc(c, (size_t)M * 64);
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s, c->b32); }));
+    ActPtr mid = actalloc(c, (size_t)M * 256);
     { GemmArgs g = conv_args(c->up1, ps, 64, H, W, 1, 1); g.act = ACT_RELU; g.outB = mid; g.ldb = 256; RUN(p_gemm(c, g, s)); }
     { GemmArgs g = conv_args(c->up3, mid, 256, H, W, 1, 1); g.outF = embed; g.ldf = c->cfg.embed_dim; RUN(p_gemm(c, g, s)); }
     return 0;
@@ -600,10 +635,10 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     const float* fpn[3] = {fpn0, fpn1, fpn2};
     const float* prior[3] = {prior8, prior16, prior32};
     const int ncls = mode == 0 ? 1 : cfg.num_classes, nch = 5 + ncls;
-    bf16* fb[3];
+    ActPtr fb[3];
     for (int k = 0; k < 3; ++k) {
-        fb[k] = wsalloc<bf16>(c, (size_t)Hk[k] * Wk[k] * ch[k]);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s); }));
+        fb[k] = actalloc(c, (size_t)Hk[k] * Wk[k] * ch[k]);
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s, c->b32); }));
     }
     int row0 = 0;
     for (int k = 0; k < 3; ++k) {
@@ -611,17 +646,17 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         const size_t mark = c->ws_off;
         float* x = wsalloc<float>(c, (size_t)M * 256);
         { Out o; o.F = x; o.ldf = 256; o.prior = prior[k]; o.pbeta = c->beta[k]; RUN(run_baseconv(c, c->stems[k], fb[k], ch[k], Hk[k], Wk[k], o, s)); }
-        bf16* t = wsalloc<bf16>(c, (size_t)M * 256);
-        bf16* hid = wsalloc<bf16>(c, (size_t)M * 1024);
-        bf16* xb = wsalloc<bf16>(c, (size_t)M * 256);
+        ActPtr t = actalloc(c, (size_t)M * 256);
+        ActPtr hid = actalloc(c, (size_t)M * 1024);
+        ActPtr xb = actalloc(c, (size_t)M * 256);
         const int nb = (int)c->att[k].size();
-        if (nb == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(x, 256, xb, 256, M, 256, s); }));
-        for (int n = 0; n < nb; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nb - 1 ? xb : nullptr, s));
-        bf16* tw = wsalloc<bf16>(c, (size_t)M * 512);      // [cls | reg] after the first (merged) tower conv
+        if (nb == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(x, 256, xb, 256, M, 256, s, c->b32); }));
+        for (int n = 0; n < nb; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nb - 1 ? xb : ActPtr(), s));
+        ActPtr tw = actalloc(c, (size_t)M * 512);      // [cls | reg] after the first (merged) tower conv
         { Out o; o.B = tw; o.ldb = 512; RUN(run_conv_gn(c, c->tower0[k], c->tower0_gn[k], 32, 1e-3f, ACT_SILU, xb, 256, Hk[k], Wk[k], 1, o, s)); }
-        bf16* cb[2] = {wsalloc<bf16>(c, (size_t)M * 256), wsalloc<bf16>(c, (size_t)M * 256)};
-        bf16* rb[2] = {wsalloc<bf16>(c, (size_t)M * 256), wsalloc<bf16>(c, (size_t)M * 256)};
-        const bf16* cls = tw; const bf16* reg = tw + 256; int ldc = 512;
+        ActPtr cb[2] = {actalloc(c, (size_t)M * 256), actalloc(c, (size_t)M * 256)};
+        ActPtr rb[2] = {actalloc(c, (size_t)M * 256), actalloc(c, (size_t)M * 256)};
+        ActPtr cls = tw, reg = tw + 256; int ldc = 512;
         for (int i = 1; i < 4; ++i) {
             { Out o; o.B = cb[i & 1]; o.ldb = 256; RUN(run_baseconv(c, c->cls_convs[k][i], cls, ldc, Hk[k], Wk[k], o, s)); }
             { Out o; o.B = rb[i & 1]; o.ldb = 256; RUN(run_baseconv(c, c->reg_convs[k][i], reg, ldc, Hk[k], Wk[k], o, s)); }
@@ -657,17 +692,17 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
             if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s); }));
         }
-        bf16* xmb = wsalloc<bf16>(c, (size_t)M8 * 128);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s); }));
-        bf16* tb[2] = {wsalloc<bf16>(c, (size_t)M8 * 128), wsalloc<bf16>(c, (size_t)M8 * 128)};
-        const bf16* cur = xmb;
+        ActPtr xmb = actalloc(c, (size_t)M8 * 128);
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
+        ActPtr tb[2] = {actalloc(c, (size_t)M8 * 128), actalloc(c, (size_t)M8 * 128)};
+        ActPtr cur = xmb;
         for (int i = 0; i < 4; ++i) {
             Out o; o.B = tb[i & 1]; o.ldb = 128;
             RUN(run_conv_gn(c, c->mtower[i], c->mtower_gn[i], 16, 1e-3f, ACT_RELU, cur, 128, Hk[0], Wk[0], 1, o, s));
             cur = tb[i & 1];
         }
         { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(p_gemm(c, g, s)); }
-        bf16* u = tb[0] == cur ? tb[1] : tb[0];
+        ActPtr u = tb[0] == cur ? tb[1] : tb[0];
         { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
         { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(p_gemm(c, g, s)); }
     }

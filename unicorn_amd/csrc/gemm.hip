@@ -37,6 +37,188 @@ __device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
         (x) = ((long)_hi << 32) | (unsigned)_lo;         \
     } while (0)
 
+// ---- shared epilogue: lane owns pixel row = m0 + wm*32*TM + i*32 + (lane&31) and, per accumulator quad g,
+// channels n0 + wn*32*TN + j*32 + 8g + 4*(lane>>5) + {0,1,2,3} ----
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                              int lane, int tid, char* smem) {
+    constexpr int BN = 64 * TN;
+    const int fr = lane & 31, fh = lane >> 5;
+    float gs[TN][16], gq[TN][16];
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gs[j][r] = 0.f; gq[j][r] = 0.f; }
+    }
+    const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * 32 * TM + i * 32 + fr;
+        const bool rok = row < p.M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cbase = n0 + wn * 32 * TN + j * 32 + 4 * fh;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = cbase + 8 * g;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (col + e < p.N) ? p.bias[col + e] : 0.f;
+                }
+                if (p.stats && rok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gs[j][4 * g + e] += v[e]; gq[j][4 * g + e] += v[e] * v[e]; }
+                }
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (col + e >= p.act_col0) ? act_apply(v[e], p.act) : v[e];
+                }
+                const bool full = vec_ok && col + 3 < p.N;
+                if (p.res && rok) {
+                    const float* rp = p.res + (size_t)row * p.ldr + col;
+                    if (full && (p.ldr & 3) == 0) {
+                        f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += rp[e];
+                    }
+                }
+                if (p.outF && rok) {
+                    float* op = p.outF + (size_t)row * p.ldf + col;
+                    if (full && (p.ldf & 3) == 0) {
+                        f32x4 o4 = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(op) = o4;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < p.N) op[e] = v[e];
+                    }
+                }
+                if (p.outB && p.b32) {
+                    if (rok) {
+                        float* op = reinterpret_cast<float*>(p.outB) + (size_t)row * p.ldb + col;
+                        if (full && (p.ldb & 3) == 0) {
+                            f32x4 o4 = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(op) = o4;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (col + e < p.N) op[e] = v[e];
+                        }
+                    }
+                } else if (p.outB) {
+                    bf16x2 lo = {(bf16)v[0], (bf16)v[1]}, hi = {(bf16)v[2], (bf16)v[3]};
+                    pk[g][0] = __builtin_bit_cast(unsigned, lo);
+                    pk[g][1] = __builtin_bit_cast(unsigned, hi);
+                }
+            }
+            if (p.outB && !p.b32) {
+                // widen to 16-B stores: after the half-swap lanes <32 hold channels 8g..8g+7 of quad pair (g,g+1),
+                // lanes >=32 hold channels 8(g+1)..8(g+1)+7
+                const int cb0 = n0 + wn * 32 * TN + j * 32;
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    const int col = cb0 + 8 * (g + fh);
+                    if (rok) {
+                        bf16* op = p.outB + (size_t)row * p.ldb + col;
+                        if ((p.ldb & 7) == 0 && col + 7 < p.N && ((reinterpret_cast<uintptr_t>(p.outB) & 15) == 0)) {
+                            u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+                            *reinterpret_cast<u32x4*>(op) = o4;
+                        } else {
+                            unsigned w4[4] = {s0[0], s1[0], s0[1], s1[1]};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (col + e < p.N) {
+                                    unsigned short h = (unsigned short)(w4[e >> 1] >> (16 * (e & 1)));
+                                    reinterpret_cast<unsigned short*>(op)[e] = h;
+                                }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // reduce over the 32 pixel lanes with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps
+        // register index r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
+        float* red = reinterpret_cast<float*>(smem);          // [2 wm][BN][2]
+        float* gacc = red + 2 * BN * 2;                       // [64][2]
+        __syncthreads();
+        if (tid < 128) gacc[tid] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s8[8], q8[8];
+            {
+                const bool up = (lane >> 4) & 1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float ss = up ? gs[j][r] : gs[j][r + 8], sq = up ? gq[j][r] : gq[j][r + 8];
+                    float ks = up ? gs[j][r + 8] : gs[j][r], kq = up ? gq[j][r + 8] : gq[j][r];
+                    s8[r] = ks + __shfl_xor(ss, 16, 64);
+                    q8[r] = kq + __shfl_xor(sq, 16, 64);
+                }
+            }
+            float s4[4], q4[4];
+            {
+                const bool up = (lane >> 3) & 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
+                    float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
+                    s4[r] = ks + __shfl_xor(ss, 8, 64);
+                    q4[r] = kq + __shfl_xor(sq, 8, 64);
+                }
+            }
+            float s2[2], q2[2];
+            {
+                const bool up = (lane >> 2) & 1;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
+                    float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
+                    s2[r] = ks + __shfl_xor(ss, 4, 64);
+                    q2[r] = kq + __shfl_xor(sq, 4, 64);
+                }
+            }
+            float s1, q1;
+            {
+                const bool up = (lane >> 1) & 1;
+                float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
+                float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
+                s1 = ks + __shfl_xor(ss, 2, 64);
+                q1 = kq + __shfl_xor(sq, 2, 64);
+            }
+            s1 += __shfl_xor(s1, 1, 64);
+            q1 += __shfl_xor(q1, 1, 64);
+            if ((lane & 1) == 0) {
+                const int r = (lane >> 1) & 15;
+                const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = q1;
+            }
+        }
+        __syncthreads();
+        const int g_first = n0 / p.cpg;
+        if (tid < BN && n0 + tid < p.N) {
+            float s = red[tid * 2] + red[(BN + tid) * 2];
+            float q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+            int gl = (n0 + tid) / p.cpg - g_first;
+            atomicAdd(&gacc[gl * 2], s);
+            atomicAdd(&gacc[gl * 2 + 1], q);
+        }
+        __syncthreads();
+        const int nloc = (min(n0 + BN, p.N) - 1) / p.cpg - g_first + 1;
+        if (tid < nloc * 2) atomicAdd(&p.stats[(g_first + (tid >> 1)) * 2 + (tid & 1)], (double)gacc[tid]);
+    }
+}
+
 template <int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 64;
@@ -153,169 +335,104 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         }
     }
 
-    // ---- epilogue: lane owns pixel row = .. + fr and, per quad g, channels col0 + 8g + 4fh + {0,1,2,3} ----
-    float gs[TN][16], gq[TN][16];
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gs[j][r] = 0.f; gq[j][r] = 0.f; }
+    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact-fp32 variant (precision mode "fp32"): same LDS-DMA / swizzle / epilogue, operands are fp32 and the
+// contraction runs on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, 157 TF peak).  64x64 block tile, BK = 32
+// floats (= the same 128-byte LDS rows).  K-permutation: MFMA step t of a K slab contracts dims {t, 16+t}.
+// ------------------------------------------------------------------------------------------------
+template <bool CONV>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    constexpr int BM = 64, BN = 64, BKF = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);               // [2][BM*BKF]
+    float* Bs = As + 2 * BM * BKF;                            // [2][BN*BKF]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const bool vec_ok = (p.N & 3) == 0;
+    const int bm = L / nbn, bn = L % nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int lrow = lane >> 3;
+    const int lch = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    const float* A = reinterpret_cast<const float*>(p.A);
+    const float* W = reinterpret_cast<const float*>(p.W);
+    const char* abase = reinterpret_cast<const char*>(A);
+    const long zoff = reinterpret_cast<const char*>(&g_zero_page) - abase;
+    int a_pix[2];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * 32 * TM + i * 32 + fr;
-        const bool rok = row < p.M;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cbase = n0 + wn * 32 * TN + j * 32 + 4 * fh;
-            unsigned pk[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cbase + 8 * g;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (p.bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (col + e < p.N) ? p.bias[col + e] : 0.f;
-                }
-                if (p.stats && rok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { gs[j][4 * g + e] += v[e]; gq[j][4 * g + e] += v[e] * v[e]; }
-                }
-                if (p.act != ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (col + e >= p.act_col0) ? act_apply(v[e], p.act) : v[e];
-                }
-                const bool full = vec_ok && col + 3 < p.N;
-                if (p.res && rok) {
-                    const float* rp = p.res + (size_t)row * p.ldr + col;
-                    if (full && (p.ldr & 3) == 0) {
-                        f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += rp[e];
-                    }
-                }
-                if (p.outF && rok) {
-                    float* op = p.outF + (size_t)row * p.ldf + col;
-                    if (full && (p.ldf & 3) == 0) {
-                        f32x4 o4 = {v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(op) = o4;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (col + e < p.N) op[e] = v[e];
-                    }
-                }
-                if (p.outB) {
-                    bf16x2 lo = {(bf16)v[0], (bf16)v[1]}, hi = {(bf16)v[2], (bf16)v[3]};
-                    pk[g][0] = __builtin_bit_cast(unsigned, lo);
-                    pk[g][1] = __builtin_bit_cast(unsigned, hi);
-                }
-            }
-            if (p.outB) {
-                // widen to 16-B stores: after the half-swap lanes <32 hold channels 8g..8g+7 of quad pair (g,g+1),
-                // lanes >=32 hold channels 8(g+1)..8(g+1)+7
-                const int cb0 = n0 + wn * 32 * TN + j * 32;
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                    const int col = cb0 + 8 * (g + fh);
-                    if (rok) {
-                        bf16* op = p.outB + (size_t)row * p.ldb + col;
-                        if ((p.ldb & 7) == 0 && col + 7 < p.N && ((reinterpret_cast<uintptr_t>(p.outB) & 15) == 0)) {
-                            u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
-                            *reinterpret_cast<u32x4*>(op) = o4;
-                        } else {
-                            unsigned w4[4] = {s0[0], s1[0], s0[1], s1[1]};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (col + e < p.N) {
-                                    unsigned short h = (unsigned short)(w4[e >> 1] >> (16 * (e & 1)));
-                                    reinterpret_cast<unsigned short*>(op)[e] = h;
-                                }
-                        }
-                    }
-                }
-            }
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + 8 * (wave + 4 * i) + lrow;
+        m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            int oy = m / p.Wout, ox = m - oy * p.Wout;
+            a_pix[i] = (oy << 16) | ox;
+        } else {
+            a_pix[i] = m;
         }
     }
-    if (p.stats) {
-        // reduce over the 32 pixel lanes with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps
-        // register index r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
-        float* red = reinterpret_cast<float*>(smem);          // [2 wm][BN][2]
-        float* gacc = red + 2 * BN * 2;                       // [64][2]
-        __syncthreads();
-        if (tid < 128) gacc[tid] = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s8[8], q8[8];
-            {
-                const bool up = (lane >> 4) & 1;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float ss = up ? gs[j][r] : gs[j][r + 8], sq = up ? gq[j][r] : gq[j][r + 8];
-                    float ks = up ? gs[j][r + 8] : gs[j][r], kq = up ? gq[j][r + 8] : gq[j][r];
-                    s8[r] = ks + __shfl_xor(ss, 16, 64);
-                    q8[r] = kq + __shfl_xor(sq, 16, 64);
-                }
-            }
-            float s4[4], q4[4];
-            {
-                const bool up = (lane >> 3) & 1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
-                    float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
-                    s4[r] = ks + __shfl_xor(ss, 8, 64);
-                    q4[r] = kq + __shfl_xor(sq, 8, 64);
-                }
-            }
-            float s2[2], q2[2];
-            {
-                const bool up = (lane >> 2) & 1;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
-                    float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
-                    s2[r] = ks + __shfl_xor(ss, 4, 64);
-                    q2[r] = kq + __shfl_xor(sq, 4, 64);
-                }
-            }
-            float s1, q1;
-            {
-                const bool up = (lane >> 1) & 1;
-                float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
-                float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
-                s1 = ks + __shfl_xor(ss, 2, 64);
-                q1 = kq + __shfl_xor(sq, 2, 64);
-            }
-            s1 += __shfl_xor(s1, 1, 64);
-            q1 += __shfl_xor(q1, 1, 64);
-            if ((lane & 1) == 0) {
-                const int r = (lane >> 1) & 15;
-                const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
-                red[(wm * BN + c) * 2 + 0] = s1;
-                red[(wm * BN + c) * 2 + 1] = q1;
-            }
+    const float* wbase = W + (size_t)(n0 + 8 * wave + lrow) * p.Kpad + lch * 4;
+    auto issue = [&](int kt, int buf) {
+        const int k = kt * BKF + lch * 4;
+        const bool kok = k < p.K;
+        char* adst = reinterpret_cast<char*>(As + buf * BM * BKF) + wave * 1024;
+        char* bdst = reinterpret_cast<char*>(Bs + buf * BN * BKF) + wave * 1024;
+        int ky = 0, kx = 0, c = k;
+        if (CONV) {
+            int tap = k / p.Cin;
+            c = k - tap * p.Cin;
+            ky = tap / p.KW;
+            kx = tap - ky * p.KW;
         }
-        __syncthreads();
-        const int g_first = n0 / p.cpg;
-        if (tid < BN && n0 + tid < p.N) {
-            float s = red[tid * 2] + red[(BN + tid) * 2];
-            float q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-            int gl = (n0 + tid) / p.cpg - g_first;
-            atomicAdd(&gacc[gl * 2], s);
-            atomicAdd(&gacc[gl * 2 + 1], q);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long off;
+            if (CONV) {
+                int oy = a_pix[i] >> 16, ox = a_pix[i] & 0xffff;
+                int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                off = ok ? (long)(((size_t)(iy * p.Win + ix) * p.lda + c) * sizeof(float)) : zoff;
+            } else {
+                off = kok ? (long)(((size_t)a_pix[i] * p.lda + k) * sizeof(float)) : zoff;
+            }
+            OPAQUE64(off);
+            GLDS16(abase + off, adst + i * 4096);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) GLDS16(wbase + (size_t)i * 32 * p.Kpad + kt * BKF, bdst + i * 4096);
+    };
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    const int nk = p.Kpad / BKF;
+    const int fr = lane & 31, fh = lane >> 5;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
         __syncthreads();
-        const int nloc = (min(n0 + BN, p.N) - 1) / p.cpg - g_first + 1;
-        if (tid < nloc * 2) atomicAdd(&p.stats[(g_first + (tid >> 1)) * 2 + (tid & 1)], (double)gacc[tid]);
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        const int arow = wm * 32 + fr, brow = wn * 32 + fr;
+        const float* a = As + buf * BM * BKF + arow * BKF;
+        const float* b = Bs + buf * BN * BKF + brow * BKF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 4 * fh + j;
+            f32x4 fa = *reinterpret_cast<const f32x4*>(a + ((ch ^ ((arow >> 1) & 7)) << 2));
+            f32x4 fb = *reinterpret_cast<const f32x4*>(b + ((ch ^ ((brow >> 1) & 7)) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], fa[e], acc[0][0], 0, 0, 0);
+        }
     }
+    gemm_epilogue<1, 1>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
 template <int TM, int TN, bool CONV>
@@ -330,9 +447,18 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     UNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-    UNI_REQUIRE(a.K % 8 == 0 && a.Kpad % 64 == 0 && a.Kpad >= a.K, "gemm: K=%d Kpad=%d", a.K, a.Kpad);
-    UNI_REQUIRE(a.lda % 8 == 0 && ((uintptr_t)a.A & 15) == 0, "gemm: lda=%d / A must be 16-byte aligned", a.lda);
+    UNI_REQUIRE(a.K % (a.b32 ? 4 : 8) == 0 && a.Kpad % 64 == 0 && a.Kpad >= a.K, "gemm: K=%d Kpad=%d", a.K, a.Kpad);
+    UNI_REQUIRE(a.lda % (a.b32 ? 4 : 8) == 0 && ((uintptr_t)a.A & 15) == 0, "gemm: lda=%d / A must be 16-byte aligned", a.lda);
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    if (a.b32) {
+        if (conv) UNI_REQUIRE(a.Cin % 4 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 65536, "gemm(f32): conv K mismatch");
+        if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
+        const int grid = cdiv(a.M, 64) * cdiv(a.N, 64);
+        const size_t lds = (size_t)2 * (64 + 64) * 32 * sizeof(float);
+        if (conv) hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3(grid), dim3(256), lds, s, a);
+        return 0;
+    }
     if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 65536, "gemm: conv K mismatch");
     if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
     // tile choice (measured on MI355X, tools/gemm_bench.py): plain GEMMs want >= ~400 blocks of 128x64, implicit

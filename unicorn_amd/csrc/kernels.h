@@ -17,6 +17,7 @@ struct GemmArgs {
     bf16* outB = nullptr; int ldb = 0;
     double* stats = nullptr; int cpg = 0;     // GroupNorm group sums [G][2] of (acc+bias), cpg = channels/group
     int force_cfg = 0;                        // 0 = heuristic, else 22 / 12 / 21 / 11
+    int b32 = 0;                              // exact-fp32 mode: A, W and outB are fp32 (v_mfma_f32_32x32x2_f32)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -31,6 +32,7 @@ struct LnArgs {
     // optional PixelShuffle(2) scatter of the bf16 output (unicorn.py:41): row=(y,x) of an (h,w) map,
     // channel c -> pixel (2y+dy, 2x+dx), channel c/4 of a (2h,2w,C/4) map
     int ps_h = 0, ps_w = 0;
+    int b32 = 0;                              // outB holds fp32 instead of bf16
 };
 int launch_layernorm(const LnArgs& a, hipStream_t s);
 
@@ -44,6 +46,7 @@ struct GnApplyArgs {
     float* outF = nullptr; int ldf = 0;
     bf16* outB = nullptr; int ldb = 0;
     bf16* outUp = nullptr; int ldu = 0; int W = 0;   // 2x nearest upsampled copy into a (2H,2W) map
+    int b32 = 0;
 };
 int launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
 
@@ -55,6 +58,7 @@ struct DwLnArgs {
     float eps = 1e-6f;
     int H = 0, W = 0, C = 0;
     bf16* out = nullptr;
+    int b32 = 0;
 };
 int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s);
 
@@ -77,6 +81,7 @@ struct MsdaFusedArgs {
     const float* offaw = nullptr; int ldo = 0;   // [Lq][192]: 128 offsets (m,l,p,xy) | 64 logits (m,l,p)
     int h = 0, w = 0;                         // both levels (h,w); Lq = 2*h*w
     bf16* out = nullptr;                      // [Lq][256]
+    int b32 = 0;
 };
 int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s);
 
@@ -87,8 +92,8 @@ int launch_corr(const float* eref, const float* ecur, const float* v, float* out
 size_t corr_workspace_bytes(int R, int Q, int K);
 
 // ---------------------------------------------------------------- misc.hip
-int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s);
-int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s);
+int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32 = 0);
+int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32 = 0);
 int launch_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, hipStream_t s);
 int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s);
 int launch_add_aligned_bilinear(const float* src, int h, int w, int C, int factor, float* dst, hipStream_t s);
@@ -109,4 +114,4 @@ struct CondInstArgs {
 int launch_condinst(const CondInstArgs& a, hipStream_t s);
 int launch_label_map_s8(const float* box_xyxy, float* out, int H, int W, hipStream_t s);
 int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,
-                        int C, hipStream_t s);
+                        int C, hipStream_t s, int b32 = 0);

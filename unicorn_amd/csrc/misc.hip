@@ -3,27 +3,27 @@
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-__global__ void cast_bf16_kernel(const float* x, int ldx, bf16* out, int ldo, int M, int C8) {
+__global__ void cast_bf16_kernel(const float* x, int ldx, bf16* out, int ldo, int M, int C8, int b32) {
     const long total = (long)M * C8;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         int m = (int)(e / C8), c = (int)(e - (long)m * C8) * 8;
         const float4* xp = reinterpret_cast<const float4*>(x + (size_t)m * ldx + c);
         float4 a = xp[0], b = xp[1];
-        bf16x8 o = {(bf16)a.x, (bf16)a.y, (bf16)a.z, (bf16)a.w, (bf16)b.x, (bf16)b.y, (bf16)b.z, (bf16)b.w};
-        *reinterpret_cast<bf16x8*>(out + (size_t)m * ldo + c) = o;
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        act_store8(out, (size_t)m * ldo + c, v, b32);
     }
 }
-int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s) {
+int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32) {
     UNI_REQUIRE(C % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0, "cast_bf16: C=%d ldx=%d ldo=%d", C, ldx, ldo);
     long total = (long)M * (C / 8);
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, x, ldx, out, ldo, M, C / 8);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, x, ldx, out, ldo, M, C / 8, b32);
     return 0;
 }
 
 // PixelShuffle(2) + cast: fp32 NHWC (h,w,C) -> bf16 NHWC (2h,2w,C/4); in channel c*4+dy*2+dx -> out (2y+dy,2x+dx,c)
-__global__ void pixel_shuffle_kernel(const float* x, bf16* out, int h, int w, int C) {
+__global__ void pixel_shuffle_kernel(const float* x, bf16* out, int h, int w, int C, int b32) {
     const int Co = C >> 2;
     const long total = (long)4 * h * w * Co;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -31,15 +31,15 @@ __global__ void pixel_shuffle_kernel(const float* x, bf16* out, int h, int w, in
         long pix = e / Co;
         int ox = (int)(pix % (2 * w)), oy = (int)(pix / (2 * w));
         int y = oy >> 1, xx = ox >> 1, dy = oy & 1, dx = ox & 1;
-        out[e] = (bf16)x[((size_t)y * w + xx) * C + c * 4 + dy * 2 + dx];
+        act_store1(out, (size_t)e, x[((size_t)y * w + xx) * C + c * 4 + dy * 2 + dx], b32);
     }
 }
-int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s) {
+int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32) {
     UNI_REQUIRE(C % 4 == 0, "pixel_shuffle: C=%d", C);
     long total = (long)h * w * C;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid), dim3(256), 0, s, x, out, h, w, C);
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid), dim3(256), 0, s, x, out, h, w, C, b32);
     return 0;
 }
 
@@ -326,7 +326,7 @@ int launch_condinst(const CondInstArgs& a, hipStream_t s) {
 
 // deformable_transformer.py:74,124: query = src + pos + level_embed[lvl] (bf16 operand of the offset/weight Linears)
 __global__ void add_pos_kernel(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out,
-                               int hw, int C) {
+                               int hw, int C, int b32) {
     const int C4 = C >> 2;
     const long total = (long)2 * hw * C4;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -337,15 +337,14 @@ __global__ void add_pos_kernel(const float* src, const float* pos0, const float*
         float4 a = *reinterpret_cast<const float4*>(src + (size_t)m * C + c);
         float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(m - l * hw) * C + c);
         float4 d = *reinterpret_cast<const float4*>(lvl + l * C + c);
-        bf16x4 o = {(bf16)(a.x + (b.x + d.x)), (bf16)(a.y + (b.y + d.y)), (bf16)(a.z + (b.z + d.z)), (bf16)(a.w + (b.w + d.w))};
-        *reinterpret_cast<bf16x4*>(out + (size_t)m * C + c) = o;
+        act_store4(out, (size_t)m * C + c, a.x + (b.x + d.x), a.y + (b.y + d.y), a.z + (b.z + d.z), a.w + (b.w + d.w), b32);
     }
 }
 int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,
-                        int C, hipStream_t s) {
+                        int C, hipStream_t s, int b32) {
     long total = (long)2 * hw * (C / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, s, src, pos0, pos1, lvl, out, hw, C);
+    hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, s, src, pos0, pos1, lvl, out, hw, C, b32);
     return 0;
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs p) {
                 acc += (w8[l * 4 + pt] * inv) * msda_bilinear(vb, p.h, p.w, 256, y, x);
         }
     }
-    p.out[idx] = (bf16)acc;
+    act_store1(p.out, (size_t)idx, acc, p.b32);
 }
 
 int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s) {

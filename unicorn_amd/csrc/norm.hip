@@ -52,14 +52,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                 if (p.ps_h) {   // PixelShuffle(2) scatter: channel c=4*idx+{0..3} -> (dy,dx) = (j>>1, j&1), out ch idx
                     int y = row / p.ps_w, xx = row - y * p.ps_w;
                     int C4o = p.C >> 2, W2 = 2 * p.ps_w;
-                    bf16* ob = p.outB + ((size_t)(2 * y) * W2 + 2 * xx) * C4o + idx;
-                    ob[0] = (bf16)o.x;
-                    ob[C4o] = (bf16)o.y;
-                    ob[(size_t)W2 * C4o] = (bf16)o.z;
-                    ob[(size_t)W2 * C4o + C4o] = (bf16)o.w;
+                    size_t ob = ((size_t)(2 * y) * W2 + 2 * xx) * C4o + idx;
+                    act_store1(p.outB, ob, o.x, p.b32);
+                    act_store1(p.outB, ob + C4o, o.y, p.b32);
+                    act_store1(p.outB, ob + (size_t)W2 * C4o, o.z, p.b32);
+                    act_store1(p.outB, ob + (size_t)W2 * C4o + C4o, o.w, p.b32);
                 } else {
-                    bf16x4 ob = {(bf16)o.x, (bf16)o.y, (bf16)o.z, (bf16)o.w};
-                    *reinterpret_cast<bf16x4*>(p.outB + (size_t)row * p.ldb + idx * 4) = ob;
+                    act_store4(p.outB, (size_t)row * p.ldb + idx * 4, o.x, o.y, o.z, o.w, p.b32);
                 }
             }
         }
@@ -120,20 +119,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
             op[0] = make_float4(v[0], v[1], v[2], v[3]);
             op[1] = make_float4(v[4], v[5], v[6], v[7]);
         }
-        if (p.outB || p.outUp) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-            if (p.outB) *reinterpret_cast<bf16x8*>(p.outB + (size_t)m * p.ldb + c) = o;
-            if (p.outUp) {
-                int y = m / p.W, x = m - y * p.W;
-                size_t W2 = 2 * (size_t)p.W;
-                bf16* u = p.outUp + ((size_t)(2 * y) * W2 + 2 * x) * p.ldu + c;
-                *reinterpret_cast<bf16x8*>(u) = o;
-                *reinterpret_cast<bf16x8*>(u + p.ldu) = o;
-                *reinterpret_cast<bf16x8*>(u + W2 * p.ldu) = o;
-                *reinterpret_cast<bf16x8*>(u + W2 * p.ldu + p.ldu) = o;
-            }
+        if (p.outB) act_store8(p.outB, (size_t)m * p.ldb + c, v, p.b32);
+        if (p.outUp) {
+            int y = m / p.W, x = m - y * p.W;
+            size_t W2 = 2 * (size_t)p.W;
+            size_t u = ((size_t)(2 * y) * W2 + 2 * x) * p.ldu + c;
+            act_store8(p.outUp, u, v, p.b32);
+            act_store8(p.outUp, u + p.ldu, v, p.b32);
+            act_store8(p.outUp, u + W2 * p.ldu, v, p.b32);
+            act_store8(p.outUp, u + W2 * p.ldu + p.ldu, v, p.b32);
         }
     }
 }
@@ -256,9 +250,9 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
     for (int o = 0; o < 8; ++o) {
         if (x0 + o < p.W) {
             float rstd = 1.f / sqrtf(tot[o] / C + p.eps);
-            bf16x4 ob = {(bf16)((acc[o].x - mean[o]) * rstd * g.x + be.x), (bf16)((acc[o].y - mean[o]) * rstd * g.y + be.y),
-                         (bf16)((acc[o].z - mean[o]) * rstd * g.z + be.z), (bf16)((acc[o].w - mean[o]) * rstd * g.w + be.w)};
-            *reinterpret_cast<bf16x4*>(p.out + ((size_t)y * p.W + x0 + o) * C + cg * 4) = ob;
+            act_store4(p.out, ((size_t)y * p.W + x0 + o) * C + cg * 4, (acc[o].x - mean[o]) * rstd * g.x + be.x,
+                       (acc[o].y - mean[o]) * rstd * g.y + be.y, (acc[o].z - mean[o]) * rstd * g.z + be.z,
+                       (acc[o].w - mean[o]) * rstd * g.w + be.w, p.b32);
         }
     }
 }

@@ -116,7 +116,12 @@ class UnicornHeadMask(UnicornHead):
 
 
 class Unicorn:
-    def __init__(self, name_or_cfg="unicorn_track_tiny", device=None):
+    def __init__(self, name_or_cfg="unicorn_track_tiny", device=None, precision="bf16"):
+        """precision: "bf16" (MFMA bf16 operands, fp32 accumulate; the benchmark configuration) or "fp32" (exact-fp32
+        MFMA everywhere; the parity mode that meets box IoU >= 0.999 against the fp32 reference)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
         cfg = dict(MODEL_CONFIGS[name_or_cfg]) if isinstance(name_or_cfg, str) else dict(name_or_cfg)
         self.cfg_name = name_or_cfg if isinstance(name_or_cfg, str) else "custom"
         self.dims, self.depths = tuple(cfg["dims"]), tuple(cfg["depths"])
@@ -152,6 +157,7 @@ class Unicorn:
             c.depths[:] = self.depths
             c.num_classes, c.mask, c.n_layer_att = self.num_classes, int(self.mask), self.n_layer_att
             c.embed_dim, c.up_rate, c.d_rate = self.embed_dim, self.up_rate, self.d_rate
+            c.precision = 1 if self.precision == "fp32" else 0
             ctx = L.lib().uni_ctx_create(idx, C.byref(c))
             if not ctx:
                 raise L.UnicornHipError("uni_ctx_create: %s" % L.lib().uni_last_error().decode())
