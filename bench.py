@@ -117,9 +117,13 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # result gather (fixed-stride rows), outside the timed region like the reference's end-of-eval gather
-        gathered = [torch.empty_like(results) for _ in range(world)]
-        dist.all_gather(gathered, results)
+        # result gather (fixed-stride rows over RCCL), outside the timed region like the reference's end-of-eval gather
+        from unicorn_amd.parallel import gather_result_rows
+        rows = results.clone()
+        rows[:, 0] = rank
+        rows[:, 1] = torch.arange(rows.shape[0], device=dev)
+        table = gather_result_rows(rows)
+        assert table.shape[0] == world * rows.shape[0]
     fps = world * args.steps / dt
 
     # ---------------- roofline leg: per-kernel-class HIP-event timing on the launch stream (rank 0) ----------------

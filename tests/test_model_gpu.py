@@ -246,3 +246,30 @@ def test_whole_mot_mode_matches_head_with_zero_priors():
         m.head(None, None, mode="bogus")
     with pytest.raises(ValueError):
         m(imgs=frames[1].cuda(), mode="nonsense")
+
+
+def test_sot_tracker_and_postprocess_match_oracle_decision():
+    """UnicornSOTTrack (mirror of external/lib/test/tracker/unicorn_sot.py) on the exact-fp32 mode: the integer box
+    it reports must equal the oracle's decision (postprocess conf 0.001 / nms 0.65, clamp, index 0, int truncation)."""
+    from unicorn_amd.tracker import UnicornSOTTrack
+    from unicorn_amd.utils.boxes import postprocess
+    m, cfg, P = build("unicorn_track_tiny", "fp32")
+    H = W = 320
+    frames, box = synth.synth_clip(H, W, 3, seed=1)
+    trk = UnicornSOTTrack(m, input_size=(H, W))
+    xywh = [float(box[0]), float(box[1]), float(box[2] - box[0]), float(box[3] - box[1])]
+    trk.initialize(frames[0].cuda(), {"init_bbox": xywh})
+    got = [trk.track(frames[i].cuda())["target_bbox"] for i in (1, 2)]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        st = uo.sot_init(P, cfg, frames[0], box)
+        exp = []
+        for i in (1, 2):
+            o = uo.sot_step(P, cfg, st, frames[i])
+            det = uo.postprocess(o["head"].clone(), 1, 0.001, 0.65)[0]
+            exp.append(uo.sot_pick_box(det, H, W))
+            if i == 1:   # HIP-side postprocess on the oracle's head output: same kept rows, same order
+                hd = postprocess(o["head"].clone().cuda(), 1, 0.001, 0.65)[0]
+                assert hd.shape == det.shape and torch.allclose(hd.cpu(), det, atol=1e-4)
+    for a, b in zip(got, exp):
+        assert all(abs(x - y) <= 1 for x, y in zip(a, b)), (got, exp)     # int truncation may flip by 1 px

@@ -49,6 +49,7 @@ struct uni_ctx {
     char* ws = nullptr; size_t ws_cap = 0, ws_off = 0; bool ws_overflow = false;
     double* stats = nullptr; int stats_slot = 0;
     bool prof_on = false; std::vector<ProfRec> recs;
+    hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[2] = {nullptr, nullptr};
 };
 
 uint16_t f32_to_bf16_host(float f);

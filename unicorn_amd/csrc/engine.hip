@@ -281,6 +281,11 @@ int engine_finalize(uni_ctx* c) {
     // GroupNorm statistics arena (zeroed at the start of every stage call)
     UNI_CHECK_HIP(hipMalloc(&c->stats, UNI_STATS_SLOTS * 64 * sizeof(double)));
     c->dev_allocs.push_back(c->stats);
+    for (int i = 0; i < 2; ++i) {
+        UNI_CHECK_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        UNI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    UNI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     UNI_REQUIRE(!c->failed, "finalize: device upload failed");
     c->host.clear();      // host copies are no longer needed
     c->finalized = true;
@@ -291,7 +296,7 @@ int engine_finalize(uni_ctx* c) {
 // workspace
 // ------------------------------------------------------------------------------------------------
 int engine_reserve(uni_ctx* c, int H, int W) {
-    const size_t need = (size_t)H * W * 3200 + ((size_t)96 << 20);
+    const size_t need = (size_t)H * W * 3200 + ((size_t)96 << 20);   // >= head: 3 level slices (H*W/64*14336 B each) + casts + mask branch
     if (need <= c->ws_cap) return 0;
     UNI_CHECK_HIP(hipSetDevice(c->device));
     UNI_CHECK_HIP(hipDeviceSynchronize());    // growing is rare; never happens inside a timed loop after warm-up
@@ -640,9 +645,22 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         fb[k] = actalloc(c, (size_t)Hk[k] * Wk[k] * ch[k]);
         RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s, c->b32); }));
     }
-    int row0 = 0;
+    // The three FPN levels are independent until the decode: run them concurrently (the stride-16/32 levels are
+    // far too small to fill 256 CUs on their own).  Level k gets its own stream and a disjoint workspace slice.
+    const bool fork = c->aux[0] && c->aux[1];
+    hipStream_t s_main = s;
+    if (fork) {
+        UNI_CHECK_HIP(hipEventRecord(c->ev_fork, s_main));
+        for (int i = 0; i < 2; ++i) UNI_CHECK_HIP(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+    }
+    const size_t lvl_base = (c->ws_off + 255) & ~(size_t)255;
+    const size_t M0 = (size_t)Hk[0] * Wk[0];
+    const size_t slice_bytes = ((M0 * 16384) + 65536 + 255) & ~(size_t)255;   // >= per-level footprint at level 0 (bf16 9.2 KB/pixel, fp32 15.4 KB/pixel)
+    const int row_start[3] = {0, Hk[0] * Wk[0], Hk[0] * Wk[0] + Hk[1] * Wk[1]};
     for (int k = 0; k < 3; ++k) {
         const int M = Hk[k] * Wk[k];
+        const int row0 = row_start[k];
+        if (fork) { s = k == 0 ? s_main : c->aux[k - 1]; c->ws_off = lvl_base + (size_t)k * slice_bytes; }
         const size_t mark = c->ws_off;
         float* x = wsalloc<float>(c, (size_t)M * 256);
         { Out o; o.F = x; o.ldf = 256; o.prior = prior[k]; o.pbeta = c->beta[k]; RUN(run_baseconv(c, c->stems[k], fb[k], ch[k], Hk[k], Wk[k], o, s)); }
@@ -678,8 +696,15 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             g.outF = dyn_params + (size_t)row0 * 169; g.ldf = 169;
             RUN(p_gemm(c, g, s));
         }
-        row0 += M;
-        c->ws_off = mark;
+        if (!fork) c->ws_off = mark;
+    }
+    s = s_main;
+    if (fork) {
+        for (int i = 0; i < 2; ++i) {
+            UNI_CHECK_HIP(hipEventRecord(c->ev_join[i], c->aux[i]));
+            UNI_CHECK_HIP(hipStreamWaitEvent(s_main, c->ev_join[i], 0));
+        }
+        c->ws_off = lvl_base + 3 * slice_bytes;
     }
     RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, Hk[0] * Wk[0], Wk[0], Hk[1] * Wk[1], Wk[1], Hk[2] * Wk[2], Wk[2], nch, s); }));
     if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162
@@ -715,5 +740,7 @@ void engine_destroy(uni_ctx* c) {
     (void)hipDeviceSynchronize();
     for (void* p : c->dev_allocs) (void)hipFree(p);
     if (c->ws) (void)hipFree(c->ws);
+    for (int i = 0; i < 2; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }

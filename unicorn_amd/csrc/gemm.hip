@@ -39,13 +39,13 @@ __device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
 
 // ---- shared epilogue: lane owns pixel row = m0 + wm*32*TM + i*32 + (lane&31) and, per accumulator quad g,
 // channels n0 + wn*32*TN + j*32 + 8g + 4*(lane>>5) + {0,1,2,3} ----
-template <int TM, int TN>
+template <int TM, int TN, bool STATS>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int lane, int tid, char* smem) {
     constexpr int BN = 64 * TN;
     const int fr = lane & 31, fh = lane >> 5;
-    float gs[TN][16], gq[TN][16];
-    if (p.stats) {
+    float gs[STATS ? TN : 1][16], gq[STATS ? TN : 1][16];
+    if (STATS) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -70,9 +70,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (col + e < p.N) ? p.bias[col + e] : 0.f;
                 }
-                if (p.stats && rok) {
+                if (STATS && rok) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { gs[j][4 * g + e] += v[e]; gq[j][4 * g + e] += v[e] * v[e]; }
+                    for (int e = 0; e < 4; ++e) { gs[STATS ? j : 0][4 * g + e] += v[e]; gq[STATS ? j : 0][4 * g + e] += v[e] * v[e]; }
                 }
                 if (p.act != ACT_NONE) {
 #pragma unroll
@@ -145,7 +145,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             }
         }
     }
-    if (p.stats) {
+    if (STATS) {
         // reduce over the 32 pixel lanes with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps
         // register index r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
         float* red = reinterpret_cast<float*>(smem);          // [2 wm][BN][2]
@@ -219,7 +219,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     }
 }
 
-template <int TM, int TN, bool CONV>
+template <int TM, int TN, bool CONV, bool STATS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 64;
     constexpr int A_PC = BM / 32;   // 1-KiB pieces (8 rows x 128 B) per wave for the A tile
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         }
     }
 
-    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+    gemm_epilogue<TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], fa[e], acc[0][0], 0, 0, 0);
         }
     }
-    gemm_epilogue<1, 1>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+    if (p.stats) gemm_epilogue<1, 1, true>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+    else gemm_epilogue<1, 1, false>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
 template <int TM, int TN, bool CONV>
@@ -441,7 +442,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
     size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16);
     if (lds < (2 * BN * 2 + 128) * sizeof(float)) lds = (2 * BN * 2 + 128) * sizeof(float);
-    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, CONV>), dim3(grid), dim3(256), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, CONV, true>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, CONV, false>), dim3(grid), dim3(256), lds, s, a);
     return 0;
 }
 
@@ -474,6 +476,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
 #define GO(TM, TN) return conv ? launch_cfg<TM, TN, true>(a, s) : launch_cfg<TM, TN, false>(a, s)
     switch (cfg) {
+        case 42: GO(4, 2);
+        case 24: GO(2, 4);
         case 22: GO(2, 2);
         case 12: GO(1, 2);
         case 21: GO(2, 1);

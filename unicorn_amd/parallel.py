@@ -1,0 +1,45 @@
+"""Multi-GPU sharding for the per-frame path.
+
+The path shards by independent video streams, one process per GPU, exactly like the reference's own SOT/VOS
+harness (external/lib/test/evaluation/running.py:111-120,199-202: sequence i -> GPU i % num_gpu).  There is no
+exchange step inside a frame, so the only collective is the end-of-run gather of fixed-stride result rows,
+which replaces the reference's pickled gloo gather (unicorn/utils/dist.py:224-265) and the tmpdir collect of
+external/qdtrack/qdtrack/apis/test_omni.py:199-233.  Backend "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo"
+in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+ROW = 8   # [stream, frame, id, x1, y1, x2, y2, score]
+
+
+def shard_streams(n_streams, world_size, rank):
+    """stream i -> rank i % world_size (running.py:114-118)."""
+    return [i for i in range(n_streams) if i % world_size == rank]
+
+
+def gather_result_rows(rows, group=None):
+    """rows: (n_i, ROW) float32 tensor of this rank (n_i may differ per rank).  Returns the concatenation over
+    ranks in rank order on EVERY rank (rows sorted by (stream, frame) afterwards).  Two collectives: an all_gather
+    of the counts, then an all_gather of rows padded to the max count (fixed stride, no pickling)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return _sort(rows)
+    world = dist.get_world_size(group)
+    dev = rows.device
+    n = torch.tensor([rows.shape[0]], device=dev, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    pad = torch.zeros((mx, ROW), device=dev, dtype=torch.float32)
+    pad[:rows.shape[0]] = rows
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return _sort(torch.cat([o[:c] for o, c in zip(out, counts)], 0))
+
+
+def _sort(rows):
+    if rows.shape[0] == 0:
+        return rows
+    key = rows[:, 0].double() * 1e9 + rows[:, 1].double()
+    return rows[torch.argsort(key, stable=True)]
