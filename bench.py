@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent video streams multiplexed on one GPU (own HIP stream + context each)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -60,20 +61,41 @@ def main():
     H, W = args.height, args.width
     cfg = uo.CONFIGS[args.model]
     P = synth.synth_state_dict(cfg)
-    model = Unicorn(args.model).cuda(local_rank)
-    model.load_state_dict(P)
-    # one independent synthetic stream per rank (seed = rank), frames resident in HBM
+    S = max(1, args.streams_per_gpu)
+    models = []
+    for _ in range(S):
+        mdl = Unicorn(args.model).cuda(local_rank)
+        mdl.load_state_dict(P)
+        models.append(mdl)
+    model = models[0]
+    hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]
+    # one independent synthetic stream per (rank, slot), frames resident in HBM
     n_frames = 4
-    frames, box = synth.synth_clip(H, W, n_frames + 1, seed=1 + rank)
-    frames = [f.to(dev) for f in frames]
-
+    clips = []
+    for j in range(S):
+        fr, bx = synth.synth_clip(H, W, n_frames + 1, seed=1 + rank * S + j)
+        clips.append(([f.to(dev) for f in fr], bx))
+    frames, box = clips[0]
+    state = []
     with torch.no_grad():
-        _, d_pre = model(imgs=frames[0], mode="backbone")          # reference frame: once, untimed
-        lbs = label_map_s8(box, H, W, dev)
+        for j in range(S):
+            _, dp = models[j](imgs=clips[j][0][0], mode="backbone")          # reference frame: once, untimed
+            state.append((dp, label_map_s8(clips[j][1], H, W, dev)))
+    torch.cuda.synchronize()
+    d_pre, lbs = state[0]
     results = torch.zeros((args.steps + args.warmup, 8), device=dev)
 
     def step(i):
-        img = frames[1 + i % n_frames]
+        if S == 1:
+            return step_one(i, 0)
+        j = i % S
+        with torch.cuda.stream(hip_streams[j]):
+            step_one(i, j)
+
+    def step_one(i, j):
+        model = models[j]
+        d_pre, lbs = state[j]
+        img = clips[j][0][1 + (i // S) % n_frames]
         with torch.no_grad():
             if args.task == "sot":
                 fpn, d_cur = model(imgs=img, mode="backbone")
@@ -199,7 +221,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s %s per-frame step %dx%d (backbone+FPN, deform interaction, embedding, fp32 correlation, "
                                    "head); one independent stream per GPU" % (args.model, args.task.upper(), H, W),
-                       "model": args.model, "task": args.task, "streams": world, "weights": "synthetic (oracle/synth.py)",
+                       "model": args.model, "task": args.task, "streams": world * S, "streams_per_gpu": S, "weights": "synthetic (oracle/synth.py)",
                        "corr_dtype": "f32", "accum": "f32"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": extra,
         }

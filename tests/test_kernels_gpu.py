@@ -48,7 +48,7 @@ def pack_weight(L, w):
 ACTS = {0: lambda x: x, 1: F.relu, 2: F.gelu, 3: F.silu, 4: torch.sigmoid}
 
 
-@pytest.mark.parametrize("cfg", [0, 22, 12, 21, 11])
+@pytest.mark.parametrize("cfg", [0, 22, 12, 21, 11, 122, 142])
 @pytest.mark.parametrize("case", [
     # (Hin, Win, Cin, N, KH, stride, pad, act, bias, res, stats_G)
     (20, 24, 96, 384, 1, 1, 0, 2, True, False, 0),        # tiny pwconv1 + GELU, K=96 (padded to 128)

@@ -20,7 +20,7 @@ SHAPES = [
     ("up1", 100, 160, 64, 256, 3, 1), ("up3", 100, 160, 256, 128, 3, 1),
     ("T.s0.pw1", 64000, 1, 96, 384, 1, 1), ("T.s2.pw1", 4000, 1, 384, 1536, 1, 1),
 ]
-cfgs = [int(a) for a in sys.argv[1:]] or [42, 24, 22, 12, 21, 11]
+cfgs = [int(a) for a in sys.argv[1:]] or [22, 21, 12, 11]
 print("%-18s %8s %6s %6s | " % ("shape", "M", "N", "K") + " ".join("%9s" % ("cfg%d" % c) for c in cfgs))
 for name, Hin, Win, Cin, N, k, stride in SHAPES:
     pad = (k - 1) // 2

@@ -157,7 +157,7 @@ int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, i
     g.M = Hout * g.Wout;
     UNI_REQUIRE(g.M == M, "gemm: M=%d does not match conv geometry (%d)", M, g.M);
     g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
-    g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
+    g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg; g.dbg = force_cfg / 1000;
     API(launch_gemm(g, S(stream)));
 }
 int uni_cast_bf16(const float* x, int ldx, uint16_t* out, int ldo, int M, int C, uni_stream_t stream) {

@@ -219,11 +219,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     }
 }
 
-template <int TM, int TN, bool CONV, bool STATS>
+template <int TM, int TN, int BK, bool CONV, bool STATS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 64;
-    constexpr int A_PC = BM / 32;   // 1-KiB pieces (8 rows x 128 B) per wave for the A tile
-    constexpr int B_PC = BN / 32;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int CPR = BK / 8;             // 16-B chunks per LDS row (row = BK bf16 = 128 B or 64 B)
+    constexpr int RPP = 64 / CPR;           // rows per 1-KiB DMA piece (8 or 16)
+    constexpr int SW = BK == 64 ? 1 : 2;    // swizzle: chunk' = chunk ^ ((row >> SW) & (CPR-1))  (256-B bank period)
+    constexpr int A_PC = BM / RPP / 4;      // 1-KiB pieces per wave for the A tile
+    constexpr int B_PC = BN / RPP / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*BK]
     bf16* Bs = As + 2 * BM * BK;                              // [2][BN*BK]
@@ -241,20 +244,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const int bm = L / nbn, bn = L % nbn;
+    // L2-friendly tile order: N is cut into chunks of 8 tiles; inside a chunk tiles run M-major, so the ~64 blocks
+    // resident on one XCD form an (8 M-panels x 8 N-tiles) super-tile that shares 16 operand K-slices per step.
+    int bm, bn;
+    {
+        const int nbm = (p.M + BM - 1) / BM;
+        constexpr int GN = 8;
+        const int per_chunk = nbm * GN;
+        const int c = L / per_chunk;
+        const int wc = min(GN, nbn - c * GN);
+        const int rem = L - c * per_chunk;
+        bm = rem / wc;
+        bn = c * GN + rem - bm * wc;
+    }
     const int m0 = bm * BM, n0 = bn * BN;
 
     // ---- per-lane DMA source descriptors ----
-    // piece pc = wave + 4*i covers tile rows 8*pc .. 8*pc+7; lane -> row 8*pc + (lane>>3), physical chunk lane&7.
-    // logical chunk = physical ^ ((row>>1)&7) = (lane&7) ^ ((4*wave + (lane>>4)) & 7)   (independent of i)
-    const int lrow = lane >> 3;
-    const int lch = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    // piece pc = wave + 4*i covers tile rows RPP*pc .. RPP*pc+RPP-1; lane -> row RPP*pc + lane/CPR, physical chunk
+    // lane%CPR; logical chunk = physical ^ swizzle(row), which is independent of i for both BK (see header).
+    const int lrow = lane / CPR;
+    const int lch = (lane % CPR) ^ (((RPP * wave + lrow) >> SW) & (CPR - 1));
     const char* abase = reinterpret_cast<const char*>(p.A);
     const long zoff = reinterpret_cast<const char*>(&g_zero_page) - abase;
     int a_pix[A_PC];
 #pragma unroll
     for (int i = 0; i < A_PC; ++i) {
-        int m = m0 + 8 * (wave + 4 * i) + lrow;
+        int m = m0 + RPP * (wave + 4 * i) + lrow;
         m = m < p.M ? m : p.M - 1;
         if (CONV) {
             int oy = m / p.Wout, ox = m - oy * p.Wout;
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             a_pix[i] = m;
         }
     }
-    const bf16* wbase = p.W + (size_t)(n0 + 8 * wave + lrow) * p.Kpad + lch * 8;
+    const bf16* wbase = p.W + (size_t)(n0 + RPP * wave + lrow) * p.Kpad + lch * 8;
 
     auto issue = [&](int kt, int buf) {
         const int k = kt * BK + lch * 8;
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < B_PC; ++i) GLDS16(wbase + (size_t)i * 32 * p.Kpad + kt * BK, bdst + i * 4096);
+        for (int i = 0; i < B_PC; ++i) GLDS16(wbase + (size_t)i * 4 * RPP * p.Kpad + kt * BK, bdst + i * 4096);
     };
 
     f32x16 acc[TM][TN];
@@ -309,29 +324,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        __syncthreads();               // tile kt landed (vmcnt(0) + barrier); everyone is done with buf^1
-        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        if (!(p.dbg & 8)) __syncthreads();               // tile kt landed (vmcnt(0) + barrier); everyone is done with buf^1
+        if (kt + 1 < nk && !(p.dbg & 1)) issue(kt + 1, buf ^ 1);
         const bf16* a = As + buf * BM * BK;
         const bf16* b = Bs + buf * BN * BK;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[TM], fb[TN];
+        // software-pipelined fragment reads: the ds_read_b128s of sub-step kk+1 are in flight while the MFMAs of
+        // sub-step kk issue (hipcc does not pipeline them across the unrolled kk loop by itself)
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto ldfrag = [&](int kk, int slot) {
             const int ch = kk * 2 + fh;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 int row = wm * 32 * TM + i * 32 + fr;
-                fa[i] = *reinterpret_cast<const bf16x8*>(a + row * BK + ((ch ^ ((row >> 1) & 7)) << 3));
+                fa[slot][i] = *reinterpret_cast<const bf16x8*>(a + row * BK + ((ch ^ ((row >> SW) & (CPR - 1))) << 3));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int row = wn * 32 * TN + j * 32 + fr;
-                fb[j] = *reinterpret_cast<const bf16x8*>(b + row * BK + ((ch ^ ((row >> 1) & 7)) << 3));
+                fb[slot][j] = *reinterpret_cast<const bf16x8*>(b + row * BK + ((ch ^ ((row >> SW) & (CPR - 1))) << 3));
             }
+        };
+        if (p.dbg & 2) continue;   // ablation: DMA only
+        if (!(p.dbg & 4) || kt == 0) ldfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if (kk + 1 < BK / 16 && (!(p.dbg & 4) || kt == 0)) ldfrag(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)   // swapped: D[n][m], lane -> pixel m = lane&31, channels 4*fh + (r&3) + 8*(r>>2)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -436,14 +458,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     else gemm_epilogue<1, 1, false>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
-template <int TM, int TN, bool CONV>
+template <int TM, int TN, int BK, bool CONV>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
-    size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16);
+    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
     if (lds < (2 * BN * 2 + 128) * sizeof(float)) lds = (2 * BN * 2 + 128) * sizeof(float);
-    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, CONV, true>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, CONV, false>), dim3(grid), dim3(256), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, BK, CONV, true>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, BK, CONV, false>), dim3(grid), dim3(256), lds, s, a);
     return 0;
 }
 
@@ -468,20 +490,23 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const long b22 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b21 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
     const long b12 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
-    int cfg = a.force_cfg;
+    int cfg = a.force_cfg % 1000;
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
         else if (conv) cfg = b22 >= 400 ? 22 : (b12 >= 400 ? 12 : 11);
         else cfg = b22 >= 2048 ? 22 : (b21 >= 400 ? 21 : 11);
     }
-#define GO(TM, TN) return conv ? launch_cfg<TM, TN, true>(a, s) : launch_cfg<TM, TN, false>(a, s)
-    switch (cfg) {
-        case 42: GO(4, 2);
-        case 24: GO(2, 4);
-        case 22: GO(2, 2);
-        case 12: GO(1, 2);
-        case 21: GO(2, 1);
-        default: GO(1, 1);
+#define GO(TM, TN, BK) return conv ? launch_cfg<TM, TN, BK, true>(a, s) : launch_cfg<TM, TN, BK, false>(a, s)
+    switch (cfg) {   // code = [1 if BK == 32] TM TN
+        case 142: GO(4, 2, 32);
+        case 124: GO(2, 4, 32);
+        case 122: GO(2, 2, 32);
+        case 112: GO(1, 2, 32);
+        case 121: GO(2, 1, 32);
+        case 22: GO(2, 2, 64);
+        case 12: GO(1, 2, 64);
+        case 21: GO(2, 1, 64);
+        default: GO(1, 1, 64);
     }
 #undef GO
 }

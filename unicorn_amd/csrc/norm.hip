@@ -6,6 +6,7 @@
 // All statistics in fp32 with a two-pass (mean, then centred variance) reduction; deterministic
 // (no float atomics).  NHWC everywhere so a wave's lanes walk the channel axis (coalesced 16-B accesses).
 #include "kernels.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, the row lives in registers (C <= 1536 -> <= 6 float4 per lane)
@@ -188,71 +189,90 @@ static size_t strip_reduce_lds(int S, int CG, int NV) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// depthwise 7x7 + bias + LayerNorm.  thread = (strip of 8 pixels along x, 4 channels); a 14-wide input
-// row window is held in registers and reused by the 7 kx taps (register sliding window).
+// depthwise 7x7 + bias + LayerNorm.  thread = (strip of PX pixels along x, 4 channels); a (PX+6)-wide input
+// row window is held in registers and reused by the 7 kx taps (register sliding window); the next input row is
+// prefetched while the current one is multiplied.  PX = 8 for big maps (fewest loads per output), PX = 4 for small
+// maps (2x the waves: the stride-16/32 maps are latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------------------
+template <int IN>
+__device__ __forceinline__ void dw_load_row(f32x4 (&dst)[IN], const DwLnArgs& p, int iy, int x0, int cg) {
+    const bool rok = iy >= 0 && iy < p.H;
+    const float* rowp = p.x + ((size_t)(rok ? iy : 0) * p.W) * p.C + cg * 4;
+#pragma unroll
+    for (int j = 0; j < IN; ++j) {
+        int ix = x0 + j - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rok && ix >= 0 && ix < p.W) v = *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * p.C);
+        dst[j] = v;
+    }
+}
+
+template <int PX>
 __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int CG, int spr, int nstrips) {
+    constexpr int IN = PX + 6;
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int cg = tid % CG, sl = tid / CG;
-    const int strip = blockIdx.x * S + sl;
+    // XCD-aware remap (block b runs on XCD b%8, private L2): give each XCD a contiguous band of strips/rows so the
+    // 7-row halo re-reads hit its own L2 instead of every XCD pulling the whole map through the fabric.
+    int blk;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int strip = blk * S + sl;
     const bool active = sl < S && strip < nstrips;
     const int y = active ? strip / spr : 0;
-    const int x0 = active ? (strip - y * spr) * 8 : 0;
+    const int x0 = active ? (strip - y * spr) * PX : 0;
     const int C = p.C;
-    float4 acc[8];
+    f32x4 acc[PX];
     {
-        float4 b = *reinterpret_cast<const float4*>(p.bias + cg * 4);
+        f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = b;
+        for (int o = 0; o < PX; ++o) acc[o] = b;
     }
     if (active) {
+        f32x4 cur[IN], nxt[IN];
+        dw_load_row<IN>(cur, p, y - 3, x0, cg);
+#pragma unroll 1
         for (int ky = 0; ky < 7; ++ky) {
-            const int iy = y + ky - 3;
-            if (iy < 0 || iy >= p.H) continue;
-            float4 in[14];
-            const float* rowp = p.x + ((size_t)iy * p.W) * C + cg * 4;
-#pragma unroll
-            for (int j = 0; j < 14; ++j) {
-                int ix = x0 + j - 3;
-                in[j] = (ix >= 0 && ix < p.W) ? *reinterpret_cast<const float4*>(rowp + (size_t)ix * C)
-                                              : make_float4(0, 0, 0, 0);
-            }
+            if (ky < 6) dw_load_row<IN>(nxt, p, y + ky - 2, x0, cg);      // prefetch the next input row
+            const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                float4 w = *reinterpret_cast<const float4*>(p.w + (size_t)(ky * 7 + kx) * C + cg * 4);
+                f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
 #pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    acc[o].x = fmaf(w.x, in[o + kx].x, acc[o].x);
-                    acc[o].y = fmaf(w.y, in[o + kx].y, acc[o].y);
-                    acc[o].z = fmaf(w.z, in[o + kx].z, acc[o].z);
-                    acc[o].w = fmaf(w.w, in[o + kx].w, acc[o].w);
+                for (int o = 0; o < PX; ++o) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[e], cur[o + kx][e], acc[o][e]);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < IN; ++j) cur[j] = nxt[j];
         }
     }
-    float part[8], tot[8];
+    float part[PX], tot[PX];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) part[o] = acc[o].x + acc[o].y + acc[o].z + acc[o].w;
-    strip_reduce<8>(part, tot, lds, S, CG, sl, cg, active);
-    float mean[8];
+    for (int o = 0; o < PX; ++o) part[o] = acc[o][0] + acc[o][1] + acc[o][2] + acc[o][3];
+    strip_reduce<PX>(part, tot, lds, S, CG, sl, cg, active);
+    float mean[PX];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
+    for (int o = 0; o < PX; ++o) {
         mean[o] = tot[o] / C;
-        float a = acc[o].x - mean[o], b = acc[o].y - mean[o], c = acc[o].z - mean[o], d = acc[o].w - mean[o];
+        float a = acc[o][0] - mean[o], b = acc[o][1] - mean[o], c = acc[o][2] - mean[o], d = acc[o][3] - mean[o];
         part[o] = a * a + b * b + c * c + d * d;
     }
-    strip_reduce<8>(part, tot, lds, S, CG, sl, cg, active);
+    strip_reduce<PX>(part, tot, lds, S, CG, sl, cg, active);
     if (!active) return;
-    const float4 g = *reinterpret_cast<const float4*>(p.gamma + cg * 4);
-    const float4 be = *reinterpret_cast<const float4*>(p.beta + cg * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + cg * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cg * 4);
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
+    for (int o = 0; o < PX; ++o) {
         if (x0 + o < p.W) {
             float rstd = 1.f / sqrtf(tot[o] / C + p.eps);
-            act_store4(p.out, ((size_t)y * p.W + x0 + o) * C + cg * 4, (acc[o].x - mean[o]) * rstd * g.x + be.x,
-                       (acc[o].y - mean[o]) * rstd * g.y + be.y, (acc[o].z - mean[o]) * rstd * g.z + be.z,
-                       (acc[o].w - mean[o]) * rstd * g.w + be.w, p.b32);
+            act_store4(p.out, ((size_t)y * p.W + x0 + o) * C + cg * 4, (acc[o][0] - mean[o]) * rstd * g[0] + be[0],
+                       (acc[o][1] - mean[o]) * rstd * g[1] + be[1], (acc[o][2] - mean[o]) * rstd * g[2] + be[2],
+                       (acc[o][3] - mean[o]) * rstd * g[3] + be[3], p.b32);
         }
     }
 }
@@ -262,10 +282,18 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     const int CG = a.C / 4;
     int S = 256 / CG;
     if (S < 1) S = 1;
-    const int spr = cdiv(a.W, 8), nstrips = spr * a.H;
     const int T = cdiv(S * CG, 64) * 64;
-    hipLaunchKernelGGL(dwconv7_ln_kernel, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 8), s, a, S, CG, spr,
-                       nstrips);
+    // PX = 8 only when the 8-pixel strips alone already give >= 8 waves per SIMD
+    static const char* env = getenv("UNI_DW_PX");
+    int px = ((long)cdiv(a.W, 8) * a.H * CG >= 64L * 8192) ? 8 : 4;
+    if (env) px = atoi(env);
+    if (px == 8) {
+        const int spr = cdiv(a.W, 8), nstrips = spr * a.H;
+        hipLaunchKernelGGL(dwconv7_ln_kernel<8>, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 8), s, a, S, CG, spr, nstrips);
+    } else {
+        const int spr = cdiv(a.W, 4), nstrips = spr * a.H;
+        hipLaunchKernelGGL(dwconv7_ln_kernel<4>, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 4), s, a, S, CG, spr, nstrips);
+    }
     return 0;
 }
 
