@@ -167,8 +167,16 @@ def main():
         g = cls["gemm"]
         peak = 2500.0   # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        traffic, tsrc = None, None
+        try:    # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+            tsrc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_hbm_traffic.json"))[-1]
+            t = json.load(open(os.path.join(ROOT, "profiles", tsrc)))["gemm_bf16_kernel"]
+            traffic = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
+        except Exception:
+            pass
         roof = {"kernel": "gemm_bf16_kernel (all instantiations)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["launches"], 1)) if "bytes" in g else None,
                 "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_frame": g["launches"],
                 "flops_per_frame": g["work"]}
         for n in ("dwconv7_ln", "gn_apply", "layernorm"):

@@ -285,7 +285,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     const int T = cdiv(S * CG, 64) * 64;
     // PX = 8 only when the 8-pixel strips alone already give >= 8 waves per SIMD
     static const char* env = getenv("UNI_DW_PX");
-    int px = ((long)cdiv(a.W, 8) * a.H * CG >= 64L * 8192) ? 8 : 4;
+    int px = ((long)cdiv(a.W, 8) * a.H * CG >= 300000L) ? 8 : 4;   // measured crossover (tools/norm_bench.py)
     if (env) px = atoi(env);
     if (px == 8) {
         const int spr = cdiv(a.W, 8), nstrips = spr * a.H;
