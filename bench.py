@@ -154,7 +154,7 @@ def main():
     if rank == 0:
         import ctypes as C
         prof_steps = 3
-        buf = (C.c_double * 15)()
+        buf = (C.c_double * 16)()
         L.check(L.lib().uni_prof_begin(model._ctx), "prof_begin")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for i in range(prof_steps):
@@ -165,6 +165,7 @@ def main():
         cls = {n: dict(ms=v[3 * i] / prof_steps, work=v[3 * i + 1] / prof_steps, launches=v[3 * i + 2] / prof_steps)
                for i, n in enumerate(names)}
         g = cls["gemm"]
+        g["bytes"] = v[15] / prof_steps
         peak = 2500.0   # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         traffic, tsrc = None, None

@@ -77,10 +77,11 @@ const char* uni_ctx_missing_name(uni_ctx* ctx, int i);
 int uni_ctx_reserve(uni_ctx* ctx, int H, int W);
 
 /* Per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg, off by default).
- * uni_prof_end synchronises the device and fills out15 = [5 classes][ms, work, launches]; classes: 0 GEMM/conv
- * (work = algorithmic FLOPs 2*M*N*K), 1 dwconv7+LN, 2 GroupNorm apply, 3 LayerNorm (work = algorithmic bytes), 4 misc. */
+ * uni_prof_end synchronises the device and fills out16: [5 classes][ms, work, launches] + out16[15] = algorithmic
+ * bytes of the GEMM class; classes: 0 GEMM/conv (work = algorithmic FLOPs 2*M*N*K), 1 dwconv7+LN, 2 GroupNorm apply,
+ * 3 LayerNorm (work = algorithmic bytes), 4 misc. */
 int uni_prof_begin(uni_ctx* ctx);
-int uni_prof_end(uni_ctx* ctx, double* out15);
+int uni_prof_end(uni_ctx* ctx, double* out16);
 
 /* ---- stage entry points (one per Unicorn.forward mode) ----------------------------------------------- */
 /* img: (1,3,H,W) fp32 NCHW.  fpn{0,1,2}: NHWC fp32 (H/8,W/8,C1), (H/16,W/16,C2), (H/32,W/32,C3).

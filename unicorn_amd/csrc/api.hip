@@ -71,7 +71,7 @@ int uni_ctx_reserve(uni_ctx* ctx, int H, int W) {
 }
 
 int uni_prof_begin(uni_ctx* ctx) { UNI_REQUIRE(ctx, "ctx is NULL"); return engine_prof_begin(ctx); }
-int uni_prof_end(uni_ctx* ctx, double* out15) { UNI_REQUIRE(ctx && out15, "prof_end: NULL argument"); return engine_prof_end(ctx, out15); }
+int uni_prof_end(uni_ctx* ctx, double* out16) { UNI_REQUIRE(ctx && out16, "prof_end: NULL argument"); return engine_prof_end(ctx, out16); }
 
 int uni_backbone_fpn(uni_ctx* ctx, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
                      uni_stream_t stream) {

@@ -48,7 +48,7 @@ struct uni_ctx {
     // scratch
     char* ws = nullptr; size_t ws_cap = 0, ws_off = 0; bool ws_overflow = false;
     double* stats = nullptr; int stats_slot = 0;
-    bool prof_on = false; std::vector<ProfRec> recs;
+    bool prof_on = false; std::vector<ProfRec> recs; double prof_bytes = 0.0;
     hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[2] = {nullptr, nullptr};
 };
 

@@ -356,6 +356,11 @@ static int prof_run(uni_ctx* c, int cls, double work, hipStream_t s, F&& f) {
     return rc;
 }
 static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
+    if (c->prof_on) {   // algorithmic bytes: input map + weights + every output/residual stream, each once
+        const double es = g.b32 ? 4.0 : 2.0;
+        c->prof_bytes += (double)g.Hin * g.Win * g.Cin * es + (double)g.N * g.K * es +
+                         (double)g.M * g.N * ((g.outF ? 4.0 : 0.0) + (g.outB ? es : 0.0) + (g.res ? 4.0 : 0.0));
+    }
     return prof_run(c, PC_GEMM, 2.0 * g.M * g.N * g.K, s, [&] { return launch_gemm(g, s); });
 }
 static int p_dwln(uni_ctx* c, DwLnArgs d, hipStream_t s) {
@@ -376,12 +381,14 @@ int engine_prof_begin(uni_ctx* c) {
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     c->recs.clear();
     c->prof_on = true;
+    c->prof_bytes = 0.0;
     return 0;
 }
-int engine_prof_end(uni_ctx* c, double* out) {   // out[PC_NCLS][3] = {ms, work, launches}
+int engine_prof_end(uni_ctx* c, double* out) {   // out[PC_NCLS][3] = {ms, work, launches}; out[15] = GEMM algorithmic bytes
     c->prof_on = false;
     UNI_CHECK_HIP(hipDeviceSynchronize());
     for (int i = 0; i < PC_NCLS * 3; ++i) out[i] = 0.0;
+    out[PC_NCLS * 3] = c->prof_bytes;
     for (auto& r : c->recs) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
