@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="frames of the stream processed per step (time-batched: the SOT step of a frame\n                    depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent video streams multiplexed on one GPU (own HIP stream + context each)")
     args = ap.parse_args()
 
@@ -92,35 +93,40 @@ def main():
         with torch.cuda.stream(hip_streams[j]):
             step_one(i, j)
 
+    NB = max(1, args.batch)
+    batches = [[torch.cat([clips[j][0][1 + (k + t) % n_frames] for t in range(NB)], 0) for k in range(n_frames)] for j in range(S)]
+
     def step_one(i, j):
         model = models[j]
         d_pre, lbs = state[j]
-        img = clips[j][0][1 + (i // S) % n_frames]
+        img = batches[j][(i // S) % n_frames]                    # (NB,3,H,W): NB consecutive frames of the stream
         with torch.no_grad():
             if args.task == "sot":
                 fpn, d_cur = model(imgs=img, mode="backbone")
                 f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
                 e_pre = model(feat=f_pre, mode="upsample")
                 e_cur = model(feat=f_cur, mode="upsample")
-                pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), lbs)
-                pri = prior_pyramid(pred.view(1, -1, d_cur["h"] * 2, d_cur["w"] * 2))
+                pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), lbs) for b in range(NB)], 0)
+                pri = prior_pyramid(pred.view(1, NB, d_cur["h"] * 2, d_cur["w"] * 2))
+                pri = tuple(t.transpose(0, 1).contiguous() for t in pri)
                 out = model.head(fpn, pri, mode="sot")
                 out = out[0] if cfg.mask else out
-                # result row = best-scoring anchor (stand-in for NMS top-1; stays on device, no sync)
-                best = torch.argmax(out[0, :, 4] * out[0, :, 5])
-                results[i, :6] = out[0, best, :6]
+                # result rows = best-scoring anchor per frame (stand-in for NMS top-1; stays on device, no sync)
+                best = torch.argmax(out[:, :, 4] * out[:, :, 5], 1)
+                results[i, :6] = out[0, best[0], :6]
             else:   # evaluate_omni-style MOT step (mot_evaluator.py:991-1034)
                 out, d_cur = model(img)
                 out = out[0] if cfg.mask else out
                 f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
                 e_cur = model(feat=f_cur, mode="upsample")
-                sc = out[0, :, 4] * out[0, :, 5:].max(1)[0]
-                top = torch.topk(sc, 64)[1]
-                b = out[0, top, :4]
-                boxes = torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
-                emb = sample_embeddings(e_cur, boxes)
-                results[i, :4] = boxes[0]
-                results[i, 4] = emb.sum()
+                for bi in range(NB):
+                    sc = out[bi, :, 4] * out[bi, :, 5:].max(1)[0]
+                    top = torch.topk(sc, 64)[1]
+                    b = out[bi, top, :4]
+                    boxes = torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
+                    emb = sample_embeddings(e_cur[bi:bi + 1], boxes)
+                    results[i, :4] = boxes[0]
+                    results[i, 4] = emb.sum()
 
     def barrier():
         if dist is not None:
@@ -146,7 +152,7 @@ def main():
         rows[:, 1] = torch.arange(rows.shape[0], device=dev)
         table = gather_result_rows(rows)
         assert table.shape[0] == world * rows.shape[0]
-    fps = world * args.steps / dt
+    fps = world * args.steps * NB / dt
 
     # ---------------- roofline leg: per-kernel-class HIP-event timing on the launch stream (rank 0) ----------------
     roof = None
@@ -162,10 +168,12 @@ def main():
         L.check(L.lib().uni_prof_end(model._ctx, buf), "prof_end")
         v = list(buf)
         names = ["gemm", "dwconv7_ln", "gn_apply", "layernorm", "misc"]
-        cls = {n: dict(ms=v[3 * i] / prof_steps, work=v[3 * i + 1] / prof_steps, launches=v[3 * i + 2] / prof_steps)
+        pf = prof_steps * NB     # per frame
+        cls = {n: dict(ms=v[3 * i] / pf, work=v[3 * i + 1] / pf, launches=v[3 * i + 2] / prof_steps)
                for i, n in enumerate(names)}
         g = cls["gemm"]
         g["bytes"] = v[15] / prof_steps
+        g["ms_step"], g["work_step"] = g["ms"] * NB, g["work"] * NB
         peak = 2500.0   # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         traffic, tsrc = None, None
@@ -178,8 +186,8 @@ def main():
         roof = {"kernel": "gemm_bf16_kernel (all instantiations)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["launches"], 1)) if "bytes" in g else None,
-                "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2), "launches_per_frame": g["launches"],
-                "flops_per_frame": g["work"]}
+                "avg_launch_us": round(1e3 * g["ms_step"] / max(g["launches"], 1), 2), "launches_per_step": g["launches"],
+                "flops_per_frame": g["work"], "flops_per_launch": round(g["work_step"] / max(g["launches"], 1))}
         for n in ("dwconv7_ln", "gn_apply", "layernorm"):
             c_ = cls[n]
             extra[n] = {"ms_per_frame": round(c_["ms"], 4), "GBps": round(c_["work"] / (c_["ms"] * 1e-3) / 1e9, 1) if c_["ms"] > 0 else 0,
@@ -191,7 +199,7 @@ def main():
                 fpn, d_cur = model(imgs=frames[1], mode="backbone")
                 f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
                 e_pre, e_cur = model(feat=f_pre, mode="upsample"), model(feat=f_cur, mode="upsample")
-                a, b = e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0)
+                a, b = e_pre[0].flatten(-2), e_cur[0].flatten(-2)
                 corr_softmax_pv(a, b, lbs)
                 ev[0].record()
                 for _ in range(5):
@@ -225,12 +233,12 @@ def main():
     if rank == 0:
         line = {
             "metric": "frames/sec @ 800x1280 %s" % args.model, "value": round(fps, 3), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "frames_per_step": NB, "ms_per_frame": round(1e3 * dt / (args.steps * NB), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "%s %s per-frame step %dx%d (backbone+FPN, deform interaction, embedding, fp32 correlation, "
-                                   "head); one independent stream per GPU" % (args.model, args.task.upper(), H, W),
-                       "model": args.model, "task": args.task, "streams": world * S, "streams_per_gpu": S, "weights": "synthetic (oracle/synth.py)",
+                                   "head); one independent stream per GPU, %d consecutive frames per step" % (args.model, args.task.upper(), H, W, NB),
+                       "model": args.model, "task": args.task, "frames_per_step": NB, "streams": world * S, "streams_per_gpu": S, "weights": "synthetic (oracle/synth.py)",
                        "corr_dtype": "f32", "accum": "f32"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": extra,
         }

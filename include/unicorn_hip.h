@@ -74,7 +74,7 @@ int uni_ctx_finalize(uni_ctx* ctx, int* n_missing);
 /* name of the i-th missing parameter after finalize (NULL when out of range) */
 const char* uni_ctx_missing_name(uni_ctx* ctx, int i);
 /* Pre-size the scratch workspace for an (H,W) input (optional; grows on demand otherwise). */
-int uni_ctx_reserve(uni_ctx* ctx, int H, int W);
+int uni_ctx_reserve(uni_ctx* ctx, int B, int H, int W);
 
 /* Per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg, off by default).
  * uni_prof_end synchronises the device and fills out16: [5 classes][ms, work, launches] + out16[15] = algorithmic
@@ -84,21 +84,22 @@ int uni_prof_begin(uni_ctx* ctx);
 int uni_prof_end(uni_ctx* ctx, double* out16);
 
 /* ---- stage entry points (one per Unicorn.forward mode) ----------------------------------------------- */
-/* img: (1,3,H,W) fp32 NCHW.  fpn{0,1,2}: NHWC fp32 (H/8,W/8,C1), (H/16,W/16,C2), (H/32,W/32,C3).
- * feat16: NHWC fp32 (H/16,W/16,C2) = seq_dict["feat"].  H, W multiples of 32. */
-int uni_backbone_fpn(uni_ctx* ctx, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2,
+/* Every stage takes a batch B of images (the reference modules are batched too; its inference drivers use B = 1).
+ * img: (B,3,H,W) fp32 NCHW.  fpn{0,1,2}: NHWC fp32 (B,H/8,W/8,C1), (B,H/16,W/16,C2), (B,H/32,W/32,C3).
+ * feat16: NHWC fp32 (B,H/16,W/16,C2) = seq_dict["feat"].  H, W multiples of 32. */
+int uni_backbone_fpn(uni_ctx* ctx, const float* img, int B, int H, int W, float* fpn0, float* fpn1, float* fpn2,
                      float* feat16, uni_stream_t stream);
-/* feat_*: NHWC fp32 (h,w,C2); pos_*: NHWC fp32 (h,w,256); out_*: NHWC fp32 (h,w,256). */
+/* feat_*: NHWC fp32 (B,h,w,C2); pos_*: NHWC fp32 (h,w,256) shared by the batch; out_*: NHWC fp32 (B,h,w,256). */
 int uni_interaction(uni_ctx* ctx, const float* feat_ref, const float* pos_ref, const float* feat_cur,
-                    const float* pos_cur, int h, int w, float* out_ref, float* out_cur, uni_stream_t stream);
-/* feat: NHWC fp32 (h,w,256) -> embed: NHWC fp32 (2h,2w,embed_dim). */
-int uni_upsample(uni_ctx* ctx, const float* feat, int h, int w, float* embed, uni_stream_t stream);
-/* fpn*: as produced by uni_backbone_fpn for an (H,W) image; prior*: (H/8*W/8), (H/16*W/16), (H/32*W/32) fp32
- * (K=1 prior per level).  mode: 0 = "sot", 1 = "mot".  out: (A, 5+nc) fp32 decoded, A = sum of level sizes,
- * nc = 1 (sot) or num_classes (mot).  Mask models additionally fill dyn_params (A,169), mask_feats
- * (H/8,W/8,8) NHWC and up_masks (H/8,W/8,9*up_rate^2) NHWC (pass NULL for box-only models). */
+                    const float* pos_cur, int B, int h, int w, float* out_ref, float* out_cur, uni_stream_t stream);
+/* feat: NHWC fp32 (B,h,w,256) -> embed: NHWC fp32 (B,2h,2w,embed_dim). */
+int uni_upsample(uni_ctx* ctx, const float* feat, int B, int h, int w, float* embed, uni_stream_t stream);
+/* fpn*: as produced by uni_backbone_fpn for B (H,W) images; prior*: (B,H/8*W/8), (B,H/16*W/16), (B,H/32*W/32) fp32
+ * (one prior per image and level).  mode: 0 = "sot", 1 = "mot".  out: (B, A, 5+nc) fp32 decoded, A = sum of level
+ * sizes, nc = 1 (sot) or num_classes (mot).  Mask models additionally fill dyn_params (B,A,169), mask_feats
+ * (B,H/8,W/8,8) NHWC and up_masks (B,H/8,W/8,9*up_rate^2) NHWC (pass NULL for box-only models). */
 int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
-             const float* prior16, const float* prior32, int H, int W, int mode, float* out, float* dyn_params,
+             const float* prior16, const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params,
              float* mask_feats, float* up_masks, uni_stream_t stream);
 int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream);
 

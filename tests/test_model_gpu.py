@@ -273,3 +273,48 @@ def test_sot_tracker_and_postprocess_match_oracle_decision():
                 assert hd.shape == det.shape and torch.allclose(hd.cpu(), det, atol=1e-4)
     for a, b in zip(got, exp):
         assert all(abs(x - y) <= 1 for x, y in zip(a, b)), (got, exp)     # int truncation may flip by 1 px
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_batched_frames_equal_single_frame_runs(precision):
+    """Every stage takes a batch of frames (M = B*H*W rows per kernel): B = 3 must reproduce three B = 1 runs
+    (per-sample GroupNorm statistics, conv halos and the head's row remap must not leak across samples).
+    Ragged 352x608: none of the per-level pixel counts is a multiple of the GEMM tiles, so tiles straddle samples."""
+    from unicorn_amd.ops import corr_softmax_pv, label_map_s8, prior_pyramid
+    m, cfg, P = build("unicorn_track_tiny_mask", precision)
+    H, W = 352, 608
+    frames, box = synth.synth_clip(H, W, 4, seed=3)
+    ref = frames[0].cuda()
+    cur = torch.cat(frames[1:4], 0).cuda()
+    with torch.no_grad():
+        _, d_pre = m(imgs=ref, mode="backbone")
+        lbs = label_map_s8(box, H, W, "cuda")
+
+        def run(x):
+            fpn, d = m(imgs=x, mode="backbone")
+            fp, fc = m(seq_dict0=d_pre, seq_dict1=d, mode="interaction")
+            ep, ec = m(feat=fp, mode="upsample"), m(feat=fc, mode="upsample")
+            pri = torch.cat([corr_softmax_pv(ep[b].flatten(-2), ec[b].flatten(-2), lbs).view(1, 1, d["h"] * 2, d["w"] * 2)
+                             for b in range(x.shape[0])], 0)
+            pp = tuple(t.transpose(0, 1).contiguous() for t in prior_pyramid(pri.transpose(0, 1).contiguous()))
+            out = m.head(fpn, pp, mode="sot")
+            return fpn, d["feat"], fc, ec, pri, out
+        big = run(cur)
+        singles = [run(cur[b:b + 1]) for b in range(3)]
+    torch.cuda.synchronize()
+    # bf16: the fp64 GN-statistics atomics arrive in a different order -> a different last bit of rstd can flip a bf16
+    # rounding, which the random-weight head then amplifies; the exact-fp32 mode pins the batching logic itself
+    tol = 2e-5 if precision == "fp32" else 1e-1
+    def close(a, b, what):
+        a, b = a.float().cpu(), b.float().cpu()
+        err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+        assert err < tol, (what, err)
+    for b in range(3):
+        for k in range(3):
+            close(big[0][k][b:b + 1], singles[b][0][k], "fpn%d" % k)
+        close(big[1][b:b + 1], singles[b][1], "feat16")
+        close(big[2][b:b + 1], singles[b][2], "feat_cur")
+        close(big[3][b:b + 1], singles[b][3], "embed_cur")
+        close(big[4][b:b + 1], singles[b][4], "prior")
+        for j in (0, 2, 4, 5):     # outputs, dynamic params, mask feats, up masks
+            close(big[5][j][b:b + 1], singles[b][5][j], "head[%d]" % j)

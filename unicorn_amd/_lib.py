@@ -24,13 +24,13 @@ PROTOS = {
     "uni_ctx_load_param": (c_i, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), c_i]),
     "uni_ctx_finalize": (c_i, [C.c_void_p, C.POINTER(c_i)]),
     "uni_ctx_missing_name": (C.c_char_p, [C.c_void_p, c_i]),
-    "uni_ctx_reserve": (c_i, [C.c_void_p, c_i, c_i]),
+    "uni_ctx_reserve": (c_i, [C.c_void_p, c_i, c_i, c_i]),
     "uni_prof_begin": (c_i, [C.c_void_p]),
     "uni_prof_end": (c_i, [C.c_void_p, C.POINTER(C.c_double)]),
-    "uni_backbone_fpn": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
-    "uni_interaction": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, C.c_void_p]),
-    "uni_upsample": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, C.c_void_p]),
-    "uni_head": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
+    "uni_backbone_fpn": (c_i, [C.c_void_p, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
+    "uni_interaction": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
+    "uni_upsample": (c_i, [C.c_void_p, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
+    "uni_head": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
     "uni_pos_embed": (c_i, [C.c_void_p, c_i, c_i, c_f, C.c_void_p]),
     "uni_msda_fwd": (c_i, [c_f, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                            C.c_void_p]),

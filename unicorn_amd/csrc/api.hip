@@ -65,34 +65,34 @@ const char* uni_ctx_missing_name(uni_ctx* ctx, int i) {
     if (!ctx || i < 0 || i >= (int)ctx->missing.size()) return nullptr;
     return ctx->missing[i].c_str();
 }
-int uni_ctx_reserve(uni_ctx* ctx, int H, int W) {
+int uni_ctx_reserve(uni_ctx* ctx, int B, int H, int W) {
     UNI_REQUIRE(ctx && ctx->finalized, "context not finalized");
-    return engine_reserve(ctx, H, W);
+    return engine_reserve(ctx, B, H, W);
 }
 
 int uni_prof_begin(uni_ctx* ctx) { UNI_REQUIRE(ctx, "ctx is NULL"); return engine_prof_begin(ctx); }
 int uni_prof_end(uni_ctx* ctx, double* out16) { UNI_REQUIRE(ctx && out16, "prof_end: NULL argument"); return engine_prof_end(ctx, out16); }
 
-int uni_backbone_fpn(uni_ctx* ctx, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
+int uni_backbone_fpn(uni_ctx* ctx, const float* img, int B, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
                      uni_stream_t stream) {
     UNI_REQUIRE(ctx && img && fpn0 && fpn1 && fpn2 && feat16, "backbone_fpn: NULL argument");
-    API(engine_backbone_fpn(ctx, img, H, W, fpn0, fpn1, fpn2, feat16, S(stream)));
+    API(engine_backbone_fpn(ctx, img, B, H, W, fpn0, fpn1, fpn2, feat16, S(stream)));
 }
 int uni_interaction(uni_ctx* ctx, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,
-                    int h, int w, float* out_ref, float* out_cur, uni_stream_t stream) {
+                    int B, int h, int w, float* out_ref, float* out_cur, uni_stream_t stream) {
     UNI_REQUIRE(ctx && feat_ref && pos_ref && feat_cur && pos_cur && out_ref && out_cur, "interaction: NULL argument");
     UNI_REQUIRE(h > 0 && w > 0, "interaction: h=%d w=%d", h, w);
-    API(engine_interaction(ctx, feat_ref, pos_ref, feat_cur, pos_cur, h, w, out_ref, out_cur, S(stream)));
+    API(engine_interaction(ctx, feat_ref, pos_ref, feat_cur, pos_cur, B, h, w, out_ref, out_cur, S(stream)));
 }
-int uni_upsample(uni_ctx* ctx, const float* feat, int h, int w, float* embed, uni_stream_t stream) {
+int uni_upsample(uni_ctx* ctx, const float* feat, int B, int h, int w, float* embed, uni_stream_t stream) {
     UNI_REQUIRE(ctx && feat && embed && h > 0 && w > 0, "upsample: bad argument");
-    API(engine_upsample(ctx, feat, h, w, embed, S(stream)));
+    API(engine_upsample(ctx, feat, B, h, w, embed, S(stream)));
 }
 int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8, const float* prior16,
-             const float* prior32, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
+             const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
              uni_stream_t stream) {
     UNI_REQUIRE(ctx && fpn0 && fpn1 && fpn2 && prior8 && prior16 && prior32 && out, "head: NULL argument");
-    API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
+    API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, B, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
 }
 int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream) {
     UNI_REQUIRE(ctx && out_nhwc && h > 0 && w > 0, "pos_embed: bad argument");

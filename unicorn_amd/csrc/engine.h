@@ -7,7 +7,7 @@
 #include "../../include/unicorn_hip.h"
 #include "kernels.h"
 
-#define UNI_STATS_SLOTS 128
+#define UNI_STATS_SLOTS 1024
 
 struct HostParam { std::vector<int64_t> shape; std::vector<float> data; };
 struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, KH = 1, KW = 1, Cin = 0, b32 = 0; };
@@ -48,6 +48,7 @@ struct uni_ctx {
     // scratch
     char* ws = nullptr; size_t ws_cap = 0, ws_off = 0; bool ws_overflow = false;
     double* stats = nullptr; int stats_slot = 0;
+    int nb = 1;   // batch size of the stage call in flight
     bool prof_on = false; std::vector<ProfRec> recs; double prof_bytes = 0.0;
     hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[2] = {nullptr, nullptr};
 };
@@ -55,15 +56,15 @@ struct uni_ctx {
 uint16_t f32_to_bf16_host(float f);
 void pack_weight_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, uint16_t* out, int Npad, int Kpad);
 int engine_finalize(uni_ctx* c);
-int engine_reserve(uni_ctx* c, int H, int W);
+int engine_reserve(uni_ctx* c, int B, int H, int W);
 int engine_prof_begin(uni_ctx* c);
 int engine_prof_end(uni_ctx* c, double* out);
 void engine_destroy(uni_ctx* c);
-int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16, hipStream_t s);
+int engine_backbone_fpn(uni_ctx* c, const float* img, int B, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16, hipStream_t s);
 int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,
-                       int h, int w, float* out_ref, float* out_cur, hipStream_t s);
-int engine_upsample(uni_ctx* c, const float* feat, int h, int w, float* embed, hipStream_t s);
+                       int B, int h, int w, float* out_ref, float* out_cur, hipStream_t s);
+int engine_upsample(uni_ctx* c, const float* feat, int B, int h, int w, float* embed, hipStream_t s);
 int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s);
 int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8, const float* prior16,
-                const float* prior32, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
+                const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
                 hipStream_t s);

@@ -295,8 +295,8 @@ int engine_finalize(uni_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
-int engine_reserve(uni_ctx* c, int H, int W) {
-    const size_t need = (size_t)H * W * 3200 + ((size_t)96 << 20);   // >= head: 3 level slices (H*W/64*14336 B each) + casts + mask branch
+int engine_reserve(uni_ctx* c, int B, int H, int W) {
+    const size_t need = (size_t)B * H * W * 3200 + ((size_t)96 << 20);   // >= head: 3 level slices (H*W/64*14336 B each) + casts + mask branch
     if (need <= c->ws_cap) return 0;
     UNI_CHECK_HIP(hipSetDevice(c->device));
     UNI_CHECK_HIP(hipDeviceSynchronize());    // growing is rare; never happens inside a timed loop after warm-up
@@ -321,20 +321,23 @@ static T* wsalloc(uni_ctx* c, size_t n) {
     return reinterpret_cast<T*>(c->ws + off);
 }
 
-static int stage_begin(uni_ctx* c, int H, int W, hipStream_t s) {
+static int stage_begin(uni_ctx* c, int B, int H, int W, hipStream_t s) {
     UNI_REQUIRE(c && c->finalized, "context not finalized");
     UNI_CHECK_HIP(hipSetDevice(c->device));
-    int rc = engine_reserve(c, H, W);
+    int rc = engine_reserve(c, B, H, W);
     if (rc) return rc;
+    c->nb = B;
     c->ws_off = 0;
     c->ws_overflow = false;
     c->stats_slot = 0;
     UNI_CHECK_HIP(hipMemsetAsync(c->stats, 0, UNI_STATS_SLOTS * 64 * sizeof(double), s));
     return 0;
 }
-static double* next_stats(uni_ctx* c) {
-    if (c->stats_slot >= UNI_STATS_SLOTS) { c->ws_overflow = true; uni_set_error("GN stats arena exhausted"); return c->stats; }
-    return c->stats + (size_t)(c->stats_slot++) * 64;
+static double* next_stats(uni_ctx* c, int n = 1) {   // n consecutive slots (one per sample)
+    if (c->stats_slot + n > UNI_STATS_SLOTS) { c->ws_overflow = true; uni_set_error("GN stats arena exhausted"); return c->stats; }
+    double* p = c->stats + (size_t)c->stats_slot * 64;
+    c->stats_slot += n;
+    return p;
 }
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; if (c->ws_overflow) return -3; } while (0)
 
@@ -420,11 +423,11 @@ struct Out {
     const float* prior = nullptr; const float* pbeta = nullptr;
 };
 
-static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, int stride, int pad) {
+static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, int stride, int pad, int B = 1) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = p.W;
     const int Hout = (Hin + 2 * pad - p.KH) / stride + 1, Wout = (Win + 2 * pad - p.KW) / stride + 1;
-    g.M = Hout * Wout; g.N = p.N; g.K = p.K; g.Kpad = p.Kpad;
+    g.Mper = Hout * Wout; g.M = B * g.Mper; g.N = p.N; g.K = p.K; g.Kpad = p.Kpad;
     g.Hin = Hin; g.Win = Win; g.Cin = p.Cin; g.KH = p.KH; g.KW = p.KW; g.stride = stride; g.pad = pad; g.Wout = Wout;
     g.bias = p.bias;
     g.b32 = p.b32;
@@ -435,14 +438,15 @@ static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, i
 static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, float eps, int act, ActPtr A, int lda,
                        int Hin, int Win, int stride, const Out& o, hipStream_t s) {
     const size_t mark = c->ws_off;
-    GemmArgs g = conv_args(conv, A, lda, Hin, Win, stride, (conv.KH - 1) / 2);
+    const int B = c->nb;
+    GemmArgs g = conv_args(conv, A, lda, Hin, Win, stride, (conv.KH - 1) / 2, B);
     float* raw = wsalloc<float>(c, (size_t)g.M * g.N);
-    double* st = next_stats(c);
+    double* st = next_stats(c, B);
     g.outF = raw; g.ldf = g.N; g.stats = st; g.cpg = g.N / G;
     RUN(p_gemm(c, g, s));
     GnApplyArgs a;
     a.x = raw; a.ldx = g.N; a.stats = st; a.gamma = gn.g; a.beta = gn.b; a.eps = eps;
-    a.M = g.M; a.C = g.N; a.G = G; a.act = act;
+    a.M = g.Mper; a.B = B; a.C = g.N; a.G = G; a.act = act;
     a.prior = o.prior; a.prior_beta = o.pbeta;
     a.outF = o.F; a.ldf = o.ldf; a.outB = o.B; a.ldb = o.ldb; a.outUp = o.Up; a.ldu = o.ldu;
     a.W = (Win + 2 * ((conv.KW - 1) / 2) - conv.KW) / stride + 1;
@@ -456,10 +460,10 @@ static int run_baseconv(uni_ctx* c, const PBaseConv& b, ActPtr A, int lda, int H
 
 // ConvNeXt block on the fp32 residual stream x [H*W][C] (in place); t/hid are caller-provided scratch
 static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr t, ActPtr hid, ActPtr outB, hipStream_t s) {
-    const int C = b.C, M = H * W;
+    const int C = b.C, M = H * W * c->nb;
     DwLnArgs d;
     d.x = x; d.w = b.dw_w; d.bias = b.dw_b; d.gamma = b.ln.g; d.beta = b.ln.b; d.eps = 1e-6f;
-    d.H = H; d.W = W; d.C = C; d.out = t;
+    d.H = H; d.W = W; d.C = C; d.B = c->nb; d.out = t;
     RUN(p_dwln(c, d, s));
     GemmArgs g1 = conv_args(b.pw1, t, C, M, 1, 1, 0);
     g1.act = ACT_GELU; g1.outB = hid; g1.ldb = 4 * C;
@@ -472,7 +476,7 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
 
 // CSP layer: cat buffer `in` [M][cin] bf16 -> `o`
 static int run_csp(uni_ctx* c, const PCsp& p, ActPtr in, int H, int W, const Out& o, hipStream_t s) {
-    const int M = H * W, h = p.h;
+    const int M = H * W * c->nb, h = p.h;
     const size_t mark = c->ws_off;
     ActPtr cat = actalloc(c, (size_t)M * 2 * h);     // [x_1 | x_2]
     ActPtr t1 = actalloc(c, (size_t)M * h);
@@ -496,50 +500,52 @@ static int run_csp(uni_ctx* c, const PCsp& p, ActPtr in, int H, int W, const Out
 // ------------------------------------------------------------------------------------------------
 // stage: backbone + PAFPN   (unicorn.py:231-258)
 // ------------------------------------------------------------------------------------------------
-int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
+int engine_backbone_fpn(uni_ctx* c, const float* img, int B, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16,
                         hipStream_t s) {
     UNI_REQUIRE(H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0, "backbone: H=%d W=%d must be positive multiples of 32", H, W);
-    RUN(stage_begin(c, H, W, s));
+    UNI_REQUIRE(B >= 1 && B <= 64, "backbone: batch %d unsupported (1..64)", B);
+    RUN(stage_begin(c, B, H, W, s));
     const int* d = c->cfg.dims;
     const int c0 = d[1], c1 = d[2], c2 = d[3];
     const int H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
-    const int M8 = H8 * W8, M16 = H16 * W16, M32 = H32 * W32;
+    const size_t M8 = (size_t)B * H8 * W8, M16 = (size_t)B * H16 * W16, M32 = (size_t)B * H32 * W32;   // rows over the batch
     // persistent (for this call) PAFPN inputs
-    ActPtr cat8 = actalloc(c, (size_t)M8 * 2 * c0);      // [up(fpn_out1) | x2]
-    ActPtr cat16a = actalloc(c, (size_t)M16 * 2 * c1);   // [up(fpn_out0) | x1]
-    ActPtr cat16b = actalloc(c, (size_t)M16 * 2 * c0);   // [p_out1 | fpn_out1]
-    ActPtr cat32 = actalloc(c, (size_t)M32 * 2 * c1);    // [p_out0 | fpn_out0]
-    ActPtr x0b = actalloc(c, (size_t)M32 * c2);
+    ActPtr cat8 = actalloc(c, M8 * 2 * c0);      // [up(fpn_out1) | x2]
+    ActPtr cat16a = actalloc(c, M16 * 2 * c1);   // [up(fpn_out0) | x1]
+    ActPtr cat16b = actalloc(c, M16 * 2 * c0);   // [p_out1 | fpn_out1]
+    ActPtr cat32 = actalloc(c, M32 * 2 * c1);    // [p_out0 | fpn_out0]
+    ActPtr x0b = actalloc(c, M32 * c2);
     // ---- ConvNeXt ----
     {
         int Hs = H / 4, Ws = W / 4;
-        float* x = wsalloc<float>(c, (size_t)Hs * Ws * d[0]);
+        float* x = wsalloc<float>(c, (size_t)B * Hs * Ws * d[0]);
         StemArgs st;
-        st.img = img; st.H = H; st.W = W; st.w = c->stem_w; st.bias = c->stem_b; st.gamma = c->stem_ln.g; st.beta = c->stem_ln.b;
+        st.img = img; st.H = H; st.W = W; st.B = B; st.w = c->stem_w; st.bias = c->stem_b; st.gamma = c->stem_ln.g; st.beta = c->stem_ln.b;
         st.C = d[0]; st.out = x;
         RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_stem(st, s); }));
         for (int i = 0; i < 4; ++i) {
             if (i > 0) {
                 // LN_cf + conv2x2/s2 (convnext.py:80-86)
-                ActPtr t = actalloc(c, (size_t)Hs * Ws * d[i - 1]);
+                ActPtr t = actalloc(c, (size_t)B * Hs * Ws * d[i - 1]);
                 LnArgs ln;
                 ln.x = x; ln.ldx = d[i - 1]; ln.gamma = c->ds_ln[i].g; ln.beta = c->ds_ln[i].b; ln.eps = 1e-6f;
-                ln.M = Hs * Ws; ln.C = d[i - 1]; ln.outB = t; ln.ldb = d[i - 1];
+                ln.M = B * Hs * Ws; ln.C = d[i - 1]; ln.outB = t; ln.ldb = d[i - 1];
                 RUN(p_ln(c, ln, s));
-                float* xn = wsalloc<float>(c, (size_t)(Hs / 2) * (Ws / 2) * d[i]);
-                GemmArgs g = conv_args(c->ds_conv[i], t, d[i - 1], Hs, Ws, 2, 0);
+                float* xn = wsalloc<float>(c, (size_t)B * (Hs / 2) * (Ws / 2) * d[i]);
+                GemmArgs g = conv_args(c->ds_conv[i], t, d[i - 1], Hs, Ws, 2, 0, B);
                 g.outF = xn; g.ldf = d[i];
                 RUN(p_gemm(c, g, s));
                 x = xn; Hs /= 2; Ws /= 2;
             }
-            const int M = Hs * Ws, C = d[i];
-            ActPtr t = actalloc(c, (size_t)M * C);
-            ActPtr hid = actalloc(c, (size_t)M * 4 * C);
+            const size_t M = (size_t)B * Hs * Ws;
+            const int C = d[i];
+            ActPtr t = actalloc(c, M * C);
+            ActPtr hid = actalloc(c, M * 4 * C);
             for (auto& b : c->blocks[i]) RUN(run_block(c, b, x, Hs, Ws, t, hid, ActPtr(), s));
             if (i >= 1) {
                 LnArgs ln;
                 ln.x = x; ln.ldx = C; ln.gamma = c->out_norm[i].g; ln.beta = c->out_norm[i].b; ln.eps = 1e-6f;
-                ln.M = M; ln.C = C;
+                ln.M = (int)M; ln.C = C;
                 if (i == 1) { ln.outB = cat8 + c0; ln.ldb = 2 * c0; }
                 else if (i == 2) { ln.outB = cat16a + c1; ln.ldb = 2 * c1; ln.outF = feat16; ln.ldf = c1; }
                 else { ln.outB = x0b; ln.ldb = c2; }
@@ -553,17 +559,17 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
         o.B = cat32 + c1; o.ldb = 2 * c1; o.Up = cat16a; o.ldu = 2 * c1;
         RUN(run_baseconv(c, c->lateral0, x0b, c2, H32, W32, o, s));
     }
-    ActPtr f_out0 = actalloc(c, (size_t)M16 * c1);
+    ActPtr f_out0 = actalloc(c, M16 * c1);
     { Out o; o.B = f_out0; o.ldb = c1; RUN(run_csp(c, c->c3p4, cat16a, H16, W16, o, s)); }
     {
         Out o;  // fpn_out1 -> cat16b[:, c0:] and upsampled into cat8[:, :c0]
         o.B = cat16b + c0; o.ldb = 2 * c0; o.Up = cat8; o.ldu = 2 * c0;
         RUN(run_baseconv(c, c->reduce1, f_out0, c1, H16, W16, o, s));
     }
-    ActPtr pan2b = actalloc(c, (size_t)M8 * c0);
+    ActPtr pan2b = actalloc(c, M8 * c0);
     { Out o; o.F = fpn0; o.ldf = c0; o.B = pan2b; o.ldb = c0; RUN(run_csp(c, c->c3p3, cat8, H8, W8, o, s)); }
     { Out o; o.B = cat16b; o.ldb = 2 * c0; RUN(run_baseconv(c, c->bu2, pan2b, c0, H8, W8, o, s)); }
-    ActPtr pan1b = actalloc(c, (size_t)M16 * c1);
+    ActPtr pan1b = actalloc(c, M16 * c1);
     { Out o; o.F = fpn1; o.ldf = c1; o.B = pan1b; o.ldb = c1; RUN(run_csp(c, c->c3n3, cat16b, H16, W16, o, s)); }
     { Out o; o.B = cat32; o.ldb = 2 * c1; RUN(run_baseconv(c, c->bu1, pan1b, c1, H16, W16, o, s)); }
     { Out o; o.F = fpn2; o.ldf = c2; RUN(run_csp(c, c->c3n4, cat32, H32, W32, o, s)); }
@@ -572,57 +578,69 @@ int engine_backbone_fpn(uni_ctx* c, const float* img, int H, int W, float* fpn0,
 
 // ------------------------------------------------------------------------------------------------
 // stage: deformable interaction   (unicorn.py:260-276, deformable_transformer.py:58-131)
+// feat_* are [B][hw][C2]; internally the tokens are laid out [B][2 frames][hw] so every sample is one contiguous
+// (ref | cur) sequence for the sampler.
 // ------------------------------------------------------------------------------------------------
 int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,
-                       int h, int w, float* out_ref, float* out_cur, hipStream_t s) {
-    RUN(stage_begin(c, h * 16, w * 16, s));
-    const int hw = h * w, L = 2 * hw, C2 = c->cfg.dims[2];
-    ActPtr fb = actalloc(c, (size_t)L * C2);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_ref, C2, fb, C2, hw, C2, s, c->b32); }));
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_cur, C2, fb + (size_t)hw * C2, C2, hw, C2, s, c->b32); }));
-    float* src = wsalloc<float>(c, (size_t)L * 256);
-    ActPtr srcb = actalloc(c, (size_t)L * 256);
-    for (int l = 0; l < 2; ++l) {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5), per frame
-        Out o; o.F = src + (size_t)l * hw * 256; o.ldf = 256; o.B = srcb + (size_t)l * hw * 256; o.ldb = 256;
-        RUN(run_conv_gn(c, c->bott, c->bott_gn, 32, 1e-5f, ACT_NONE, fb + (size_t)l * hw * C2, C2, hw, 1, 1, o, s));
+                       int B, int h, int w, float* out_ref, float* out_cur, hipStream_t s) {
+    UNI_REQUIRE(B >= 1 && B <= 32, "interaction: batch %d unsupported (1..32)", B);
+    RUN(stage_begin(c, B, h * 16, w * 16, s));
+    const int hw = h * w, C2 = c->cfg.dims[2];
+    const size_t L = (size_t)2 * hw * B;                    // tokens over the batch
+    ActPtr fb = actalloc(c, L * C2);
+    for (int b = 0; b < B; ++b) {
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_ref + (size_t)b * hw * C2, C2, fb + (size_t)(2 * b) * hw * C2, C2, hw, C2, s, c->b32); }));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_cur + (size_t)b * hw * C2, C2, fb + (size_t)(2 * b + 1) * hw * C2, C2, hw, C2, s, c->b32); }));
     }
-    ActPtr qb = actalloc(c, (size_t)L * 256);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s, c->b32); }));
-    float* value = wsalloc<float>(c, (size_t)L * 256);
-    { GemmArgs g = conv_args(c->value_proj, srcb, 256, L, 1, 1, 0); g.outF = value; g.ldf = 256; RUN(p_gemm(c, g, s)); }
-    float* offaw = wsalloc<float>(c, (size_t)L * 192);
-    { GemmArgs g = conv_args(c->offaw, qb, 256, L, 1, 1, 0); g.outF = offaw; g.ldf = 192; RUN(p_gemm(c, g, s)); }
-    ActPtr attn = actalloc(c, (size_t)L * 256);
-    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; m.b32 = c->b32; RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_msda_fused(m, s); })); }
-    float* y = wsalloc<float>(c, (size_t)L * 256);
-    { GemmArgs g = conv_args(c->output_proj, attn, 256, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
+    float* src = wsalloc<float>(c, L * 256);
+    ActPtr srcb = actalloc(c, L * 256);
+    {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5) per frame = 2B "samples" of hw rows
+        c->nb = 2 * B;
+        Out o; o.F = src; o.ldf = 256; o.B = srcb; o.ldb = 256;
+        int rc = run_conv_gn(c, c->bott, c->bott_gn, 32, 1e-5f, ACT_NONE, fb, C2, hw, 1, 1, o, s);
+        c->nb = B;
+        if (rc) return rc;
+    }
+    ActPtr qb = actalloc(c, L * 256);
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_pos_bf16(src, pos_ref, pos_cur, c->level_embed, qb, hw, 256, s, c->b32, B); }));
+    float* value = wsalloc<float>(c, L * 256);
+    { GemmArgs g = conv_args(c->value_proj, srcb, 256, (int)L, 1, 1, 0); g.outF = value; g.ldf = 256; RUN(p_gemm(c, g, s)); }
+    float* offaw = wsalloc<float>(c, L * 192);
+    { GemmArgs g = conv_args(c->offaw, qb, 256, (int)L, 1, 1, 0); g.outF = offaw; g.ldf = 192; RUN(p_gemm(c, g, s)); }
+    ActPtr attn = actalloc(c, L * 256);
+    { MsdaFusedArgs m; m.value = value; m.offaw = offaw; m.ldo = 192; m.h = h; m.w = w; m.out = attn; m.b32 = c->b32; m.B = B; RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_msda_fused(m, s); })); }
+    float* y = wsalloc<float>(c, L * 256);
+    { GemmArgs g = conv_args(c->output_proj, attn, 256, (int)L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
     {   // src = norm1(src + attn)
-        LnArgs ln; ln.x = y; ln.ldx = 256; ln.gamma = c->norm1.g; ln.beta = c->norm1.b; ln.eps = 1e-5f; ln.M = L; ln.C = 256;
+        LnArgs ln; ln.x = y; ln.ldx = 256; ln.gamma = c->norm1.g; ln.beta = c->norm1.b; ln.eps = 1e-5f; ln.M = (int)L; ln.C = 256;
         ln.outF = src; ln.ldf = 256; ln.outB = srcb; ln.ldb = 256;
         RUN(p_ln(c, ln, s));
     }
-    ActPtr hid = actalloc(c, (size_t)L * 1024);
-    { GemmArgs g = conv_args(c->lin1, srcb, 256, L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(p_gemm(c, g, s)); }
-    { GemmArgs g = conv_args(c->lin2, hid, 1024, L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
-    for (int l = 0; l < 2; ++l) {
-        LnArgs ln; ln.x = y + (size_t)l * hw * 256; ln.ldx = 256; ln.gamma = c->norm2.g; ln.beta = c->norm2.b; ln.eps = 1e-5f;
-        ln.M = hw; ln.C = 256; ln.outF = l ? out_cur : out_ref; ln.ldf = 256;
-        RUN(p_ln(c, ln, s));
-    }
+    ActPtr hid = actalloc(c, L * 1024);
+    { GemmArgs g = conv_args(c->lin1, srcb, 256, (int)L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(p_gemm(c, g, s)); }
+    { GemmArgs g = conv_args(c->lin2, hid, 1024, (int)L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < 2; ++l) {
+            LnArgs ln; ln.x = y + (size_t)(2 * b + l) * hw * 256; ln.ldx = 256; ln.gamma = c->norm2.g; ln.beta = c->norm2.b; ln.eps = 1e-5f;
+            ln.M = hw; ln.C = 256; ln.outF = (l ? out_cur : out_ref) + (size_t)b * hw * 256; ln.ldf = 256;
+            RUN(p_ln(c, ln, s));
+        }
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage: embedding head   (unicorn.py:41-44,311-313)
 // ------------------------------------------------------------------------------------------------
-int engine_upsample(uni_ctx* c, const float* feat, int h, int w, float* embed, hipStream_t s) {
-    RUN(stage_begin(c, h * 16, w * 16, s));
-    const int H = 2 * h, W = 2 * w, M = H * W;
-    ActPtr ps = actalloc(c, (size_t)M * 64);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s, c->b32); }));
-    ActPtr mid = actalloc(c, (size_t)M * 256);
-    { GemmArgs g = conv_args(c->up1, ps, 64, H, W, 1, 1); g.act = ACT_RELU; g.outB = mid; g.ldb = 256; RUN(p_gemm(c, g, s)); }
-    { GemmArgs g = conv_args(c->up3, mid, 256, H, W, 1, 1); g.outF = embed; g.ldf = c->cfg.embed_dim; RUN(p_gemm(c, g, s)); }
+int engine_upsample(uni_ctx* c, const float* feat, int B, int h, int w, float* embed, hipStream_t s) {
+    UNI_REQUIRE(B >= 1 && B <= 64, "upsample: batch %d unsupported (1..64)", B);
+    RUN(stage_begin(c, B, h * 16, w * 16, s));
+    const int H = 2 * h, W = 2 * w;
+    const size_t M = (size_t)B * H * W;
+    ActPtr ps = actalloc(c, M * 64);
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_pixel_shuffle_bf16(feat, ps, h, w, 256, s, c->b32, B); }));
+    ActPtr mid = actalloc(c, M * 256);
+    { GemmArgs g = conv_args(c->up1, ps, 64, H, W, 1, 1, B); g.act = ACT_RELU; g.outB = mid; g.ldb = 256; RUN(p_gemm(c, g, s)); }
+    { GemmArgs g = conv_args(c->up3, mid, 256, H, W, 1, 1, B); g.outF = embed; g.ldf = c->cfg.embed_dim; RUN(p_gemm(c, g, s)); }
     return 0;
 }
 
@@ -635,22 +653,25 @@ int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s) {
 // stage: unified head (+ mask branch / controllers)   (unicorn_head.py:249-336, unicorn_head_mask.py:280-372)
 // ------------------------------------------------------------------------------------------------
 int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
-                const float* prior16, const float* prior32, int H, int W, int mode, float* out, float* dyn_params,
+                const float* prior16, const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params,
                 float* mask_feats, float* up_masks, hipStream_t s) {
     UNI_REQUIRE(mode == 0 || mode == 1, "head: mode has to be 0 ('sot') or 1 ('mot')");   // unicorn_head.py:291-292
     UNI_REQUIRE(H % 32 == 0 && W % 32 == 0, "head: H=%d W=%d", H, W);
-    RUN(stage_begin(c, H, W, s));
+    UNI_REQUIRE(B >= 1 && B <= 64, "head: batch %d unsupported (1..64)", B);
+    RUN(stage_begin(c, B, H, W, s));
     const auto& cfg = c->cfg;
     if (cfg.mask) UNI_REQUIRE(dyn_params && mask_feats && up_masks, "head: mask model needs dyn_params/mask_feats/up_masks");
     const int ch[3] = {cfg.dims[1], cfg.dims[2], cfg.dims[3]};
     const int Hk[3] = {H / 8, H / 16, H / 32}, Wk[3] = {W / 8, W / 16, W / 32};
+    const int HWk[3] = {Hk[0] * Wk[0], Hk[1] * Wk[1], Hk[2] * Wk[2]};
+    const int A = HWk[0] + HWk[1] + HWk[2];                       // anchors per image
     const float* fpn[3] = {fpn0, fpn1, fpn2};
     const float* prior[3] = {prior8, prior16, prior32};
     const int ncls = mode == 0 ? 1 : cfg.num_classes, nch = 5 + ncls;
     ActPtr fb[3];
     for (int k = 0; k < 3; ++k) {
-        fb[k] = actalloc(c, (size_t)Hk[k] * Wk[k] * ch[k]);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Hk[k] * Wk[k], ch[k], s, c->b32); }));
+        fb[k] = actalloc(c, (size_t)B * HWk[k] * ch[k]);
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], B * HWk[k], ch[k], s, c->b32); }));
     }
     // The three FPN levels are independent until the decode: run them concurrently (the stride-16/32 levels are
     // far too small to fill 256 CUs on their own).  Level k gets its own stream and a disjoint workspace slice.
@@ -661,11 +682,11 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         for (int i = 0; i < 2; ++i) UNI_CHECK_HIP(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
     }
     const size_t lvl_base = (c->ws_off + 255) & ~(size_t)255;
-    const size_t M0 = (size_t)Hk[0] * Wk[0];
+    const size_t M0 = (size_t)B * HWk[0];
     const size_t slice_bytes = ((M0 * 16384) + 65536 + 255) & ~(size_t)255;   // >= per-level footprint at level 0 (bf16 9.2 KB/pixel, fp32 15.4 KB/pixel)
-    const int row_start[3] = {0, Hk[0] * Wk[0], Hk[0] * Wk[0] + Hk[1] * Wk[1]};
+    const int row_start[3] = {0, HWk[0], HWk[0] + HWk[1]};
     for (int k = 0; k < 3; ++k) {
-        const int M = Hk[k] * Wk[k];
+        const int M = B * HWk[k];                                // rows over the batch at this level
         const int row0 = row_start[k];
         if (fork) { s = k == 0 ? s_main : c->aux[k - 1]; c->ws_off = lvl_base + (size_t)k * slice_bytes; }
         const size_t mark = c->ws_off;
@@ -674,9 +695,9 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         ActPtr t = actalloc(c, (size_t)M * 256);
         ActPtr hid = actalloc(c, (size_t)M * 1024);
         ActPtr xb = actalloc(c, (size_t)M * 256);
-        const int nb = (int)c->att[k].size();
-        if (nb == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(x, 256, xb, 256, M, 256, s, c->b32); }));
-        for (int n = 0; n < nb; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nb - 1 ? xb : ActPtr(), s));
+        const int nblk = (int)c->att[k].size();
+        if (nblk == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(x, 256, xb, 256, M, 256, s, c->b32); }));
+        for (int n = 0; n < nblk; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nblk - 1 ? xb : ActPtr(), s));
         ActPtr tw = actalloc(c, (size_t)M * 512);      // [cls | reg] after the first (merged) tower conv
         { Out o; o.B = tw; o.ldb = 512; RUN(run_conv_gn(c, c->tower0[k], c->tower0_gn[k], 32, 1e-3f, ACT_SILU, xb, 256, Hk[k], Wk[k], 1, o, s)); }
         ActPtr cb[2] = {actalloc(c, (size_t)M * 256), actalloc(c, (size_t)M * 256)};
@@ -687,20 +708,23 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             { Out o; o.B = rb[i & 1]; o.ldb = 256; RUN(run_baseconv(c, c->reg_convs[k][i], reg, ldc, Hk[k], Wk[k], o, s)); }
             cls = cb[i & 1]; reg = rb[i & 1]; ldc = 256;
         }
-        float* ok = out + (size_t)row0 * nch;
+        // predictions land in out[b][row0 + p][:] (anchor order: level 8 rows, then 16, then 32, per image)
         {   // [reg(4) | sigmoid(obj)]  (unicorn_head.py:295-304,332-334)
             GemmArgs g = conv_args(mode == 0 ? c->regobj_sot[k] : c->regobj[k], reg, ldc, M, 1, 1, 0);
-            g.act = ACT_SIGMOID; g.act_col0 = 4; g.outF = ok; g.ldf = nch;
+            g.act = ACT_SIGMOID; g.act_col0 = 4; g.outF = out; g.ldf = nch;
+            g.out_hw = HWk[k]; g.out_stride = A; g.out_off = row0;
             RUN(p_gemm(c, g, s));
         }
         {   // sigmoid(cls)
             GemmArgs g = conv_args(mode == 0 ? c->cls_pred_sot[k] : c->cls_pred[k], cls, ldc, M, 1, 1, 0);
-            g.act = ACT_SIGMOID; g.outF = ok + 5; g.ldf = nch;
+            g.act = ACT_SIGMOID; g.outF = out + 5; g.ldf = nch;
+            g.out_hw = HWk[k]; g.out_stride = A; g.out_off = row0;
             RUN(p_gemm(c, g, s));
         }
         if (cfg.mask) {   // controllers on reg_feat (ctrl_loc == "reg", unicorn_head_mask.py:333-340)
-            GemmArgs g = conv_args(c->controllers[k], reg, ldc, Hk[k], Wk[k], 1, 1);
-            g.outF = dyn_params + (size_t)row0 * 169; g.ldf = 169;
+            GemmArgs g = conv_args(c->controllers[k], reg, ldc, Hk[k], Wk[k], 1, 1, B);
+            g.outF = dyn_params; g.ldf = 169;
+            g.out_hw = HWk[k]; g.out_stride = A; g.out_off = row0;
             RUN(p_gemm(c, g, s));
         }
         if (!fork) c->ws_off = mark;
@@ -713,16 +737,16 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         }
         c->ws_off = lvl_base + 3 * slice_bytes;
     }
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, Hk[0] * Wk[0], Wk[0], Hk[1] * Wk[1], Wk[1], Hk[2] * Wk[2], Wk[2], nch, s); }));
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, HWk[0], Wk[0], HWk[1], Wk[1], HWk[2], Wk[2], nch, s, B); }));
     if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162
-        const int M8 = Hk[0] * Wk[0];
+        const int M8 = B * HWk[0];
         float* xm = wsalloc<float>(c, (size_t)M8 * 128);
         for (int k = 0; k < 3; ++k) {
-            const int M = Hk[k] * Wk[k];
+            const int M = B * HWk[k];
             float* r = k == 0 ? xm : wsalloc<float>(c, (size_t)M * 128);
             Out o; o.F = r; o.ldf = 128;
             RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
-            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s); }));
+            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s, B); }));
         }
         ActPtr xmb = actalloc(c, (size_t)M8 * 128);
         RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
@@ -735,7 +759,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         }
         { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(p_gemm(c, g, s)); }
         ActPtr u = tb[0] == cur ? tb[1] : tb[0];
-        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
+        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1, B); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
         { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(p_gemm(c, g, s)); }
     }
     return 0;

@@ -44,13 +44,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                                               int lane, int tid, char* smem) {
     constexpr int BN = 64 * TN;
     const int fr = lane & 31, fh = lane >> 5;
-    float gs[STATS ? TN : 1][16], gq[STATS ? TN : 1][16];
-    if (STATS) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gs[j][r] = 0.f; gq[j][r] = 0.f; }
-    }
     const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -70,10 +63,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (col + e < p.N) ? p.bias[col + e] : 0.f;
                 }
-                if (STATS && rok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { gs[STATS ? j : 0][4 * g + e] += v[e]; gq[STATS ? j : 0][4 * g + e] += v[e] * v[e]; }
-                }
                 if (p.act != ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (col + e >= p.act_col0) ? act_apply(v[e], p.act) : v[e];
@@ -91,7 +80,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
                     }
                 }
                 if (p.outF && rok) {
-                    float* op = p.outF + (size_t)row * p.ldf + col;
+                    const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
+                    float* op = p.outF + (size_t)orow * p.ldf + col;
                     if (full && (p.ldf & 3) == 0) {
                         f32x4 o4 = {v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(op) = o4;
@@ -146,76 +136,105 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
         }
     }
     if (STATS) {
-        // reduce over the 32 pixel lanes with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps
-        // register index r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
+        // GroupNorm statistics of (acc + bias), PER SAMPLE: a block tile may straddle samples of a batch, so the
+        // reduction runs once per sample present in the tile (one iteration except at sample boundaries).
+        // Pixel lanes are reduced with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps register index
+        // r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
         float* red = reinterpret_cast<float*>(smem);          // [2 wm][BN][2]
         float* gacc = red + 2 * BN * 2;                       // [64][2]
-        __syncthreads();
-        if (tid < 128) gacc[tid] = 0.f;
+        const int b_lo = m0 / p.Mper;
+        const int b_hi = min(p.M - 1, m0 + 64 * TM - 1) / p.Mper;
+        for (int sb = b_lo; sb <= b_hi; ++sb) {
+            const int r_lo = sb * p.Mper, r_hi = min(r_lo + p.Mper, p.M);
+            float gs[TN][16], gq[TN][16];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s8[8], q8[8];
-            {
-                const bool up = (lane >> 4) & 1;
+            for (int j = 0; j < TN; ++j) {
+                const int cbase = n0 + wn * 32 * TN + j * 32 + 4 * fh;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float ss = up ? gs[j][r] : gs[j][r + 8], sq = up ? gq[j][r] : gq[j][r + 8];
-                    float ks = up ? gs[j][r + 8] : gs[j][r], kq = up ? gq[j][r + 8] : gq[j][r];
-                    s8[r] = ks + __shfl_xor(ss, 16, 64);
-                    q8[r] = kq + __shfl_xor(sq, 16, 64);
+                for (int r = 0; r < 16; ++r) {
+                    const int col = cbase + 8 * (r >> 2) + (r & 3);
+                    const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+                    float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = m0 + wm * 32 * TM + i * 32 + fr;
+                        const float v = acc[i][j][r] + bias;
+                        const bool in = row >= r_lo && row < r_hi;
+                        s_ += in ? v : 0.f;
+                        q_ += in ? v * v : 0.f;
+                    }
+                    gs[j][r] = s_;
+                    gq[j][r] = q_;
                 }
             }
-            float s4[4], q4[4];
-            {
-                const bool up = (lane >> 3) & 1;
+            __syncthreads();
+            if (tid < 128) gacc[tid] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
-                    float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
-                    s4[r] = ks + __shfl_xor(ss, 8, 64);
-                    q4[r] = kq + __shfl_xor(sq, 8, 64);
+            for (int j = 0; j < TN; ++j) {
+                float s8[8], q8[8];
+                {
+                    const bool up = (lane >> 4) & 1;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float ss = up ? gs[j][r] : gs[j][r + 8], sq = up ? gq[j][r] : gq[j][r + 8];
+                        float ks = up ? gs[j][r + 8] : gs[j][r], kq = up ? gq[j][r + 8] : gq[j][r];
+                        s8[r] = ks + __shfl_xor(ss, 16, 64);
+                        q8[r] = kq + __shfl_xor(sq, 16, 64);
+                    }
+                }
+                float s4[4], q4[4];
+                {
+                    const bool up = (lane >> 3) & 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
+                        float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
+                        s4[r] = ks + __shfl_xor(ss, 8, 64);
+                        q4[r] = kq + __shfl_xor(sq, 8, 64);
+                    }
+                }
+                float s2[2], q2[2];
+                {
+                    const bool up = (lane >> 2) & 1;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
+                        float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
+                        s2[r] = ks + __shfl_xor(ss, 4, 64);
+                        q2[r] = kq + __shfl_xor(sq, 4, 64);
+                    }
+                }
+                float s1, q1;
+                {
+                    const bool up = (lane >> 1) & 1;
+                    float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
+                    float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
+                    s1 = ks + __shfl_xor(ss, 2, 64);
+                    q1 = kq + __shfl_xor(sq, 2, 64);
+                }
+                s1 += __shfl_xor(s1, 1, 64);
+                q1 += __shfl_xor(q1, 1, 64);
+                if ((lane & 1) == 0) {
+                    const int r = (lane >> 1) & 15;
+                    const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                    red[(wm * BN + c) * 2 + 0] = s1;
+                    red[(wm * BN + c) * 2 + 1] = q1;
                 }
             }
-            float s2[2], q2[2];
-            {
-                const bool up = (lane >> 2) & 1;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
-                    float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
-                    s2[r] = ks + __shfl_xor(ss, 4, 64);
-                    q2[r] = kq + __shfl_xor(sq, 4, 64);
-                }
+            __syncthreads();
+            const int g_first = n0 / p.cpg;
+            if (tid < BN && n0 + tid < p.N) {
+                float s = red[tid * 2] + red[(BN + tid) * 2];
+                float q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+                int gl = (n0 + tid) / p.cpg - g_first;
+                atomicAdd(&gacc[gl * 2], s);
+                atomicAdd(&gacc[gl * 2 + 1], q);
             }
-            float s1, q1;
-            {
-                const bool up = (lane >> 1) & 1;
-                float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
-                float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
-                s1 = ks + __shfl_xor(ss, 2, 64);
-                q1 = kq + __shfl_xor(sq, 2, 64);
-            }
-            s1 += __shfl_xor(s1, 1, 64);
-            q1 += __shfl_xor(q1, 1, 64);
-            if ((lane & 1) == 0) {
-                const int r = (lane >> 1) & 15;
-                const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
-                red[(wm * BN + c) * 2 + 0] = s1;
-                red[(wm * BN + c) * 2 + 1] = q1;
-            }
+            __syncthreads();
+            const int nloc = (min(n0 + BN, p.N) - 1) / p.cpg - g_first + 1;
+            if (tid < nloc * 2)
+                atomicAdd(&p.stats[(size_t)sb * 64 + (g_first + (tid >> 1)) * 2 + (tid & 1)], (double)gacc[tid]);
         }
-        __syncthreads();
-        const int g_first = n0 / p.cpg;
-        if (tid < BN && n0 + tid < p.N) {
-            float s = red[tid * 2] + red[(BN + tid) * 2];
-            float q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-            int gl = (n0 + tid) / p.cpg - g_first;
-            atomicAdd(&gacc[gl * 2], s);
-            atomicAdd(&gacc[gl * 2 + 1], q);
-        }
-        __syncthreads();
-        const int nloc = (min(n0 + BN, p.N) - 1) / p.cpg - g_first + 1;
-        if (tid < nloc * 2) atomicAdd(&p.stats[(g_first + (tid >> 1)) * 2 + (tid & 1)], (double)gacc[tid]);
     }
 }
 
@@ -272,8 +291,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         int m = m0 + RPP * (wave + 4 * i) + lrow;
         m = m < p.M ? m : p.M - 1;
         if (CONV) {
-            int oy = m / p.Wout, ox = m - oy * p.Wout;
-            a_pix[i] = (oy << 16) | ox;
+            int b = m / p.Mper, q = m - b * p.Mper;        // sample, pixel within the sample
+            int oy = q / p.Wout, ox = q - oy * p.Wout;
+            a_pix[i] = (b << 24) | (oy << 12) | ox;
         } else {
             a_pix[i] = m;
         }
@@ -291,10 +311,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
             for (int i = 0; i < A_PC; ++i) {
-                int oy = a_pix[i] >> 16, ox = a_pix[i] & 0xffff;
+                int bb = a_pix[i] >> 24, oy = (a_pix[i] >> 12) & 0xfff, ox = a_pix[i] & 0xfff;
                 int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
                 bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                long off = ok ? (long)(((size_t)(iy * p.Win + ix) * p.lda + c) * sizeof(bf16)) : zoff;
+                long off = ok ? (long)(((size_t)((bb * p.Hin + iy) * p.Win + ix) * p.lda + c) * sizeof(bf16)) : zoff;
                 OPAQUE64(off);   // keep ONE DMA per piece (hipcc otherwise splits the select into exec-masked branches)
                 GLDS16(abase + off, adst + i * 4096);
             }
@@ -396,8 +416,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         int m = m0 + 8 * (wave + 4 * i) + lrow;
         m = m < p.M ? m : p.M - 1;
         if (CONV) {
-            int oy = m / p.Wout, ox = m - oy * p.Wout;
-            a_pix[i] = (oy << 16) | ox;
+            int b = m / p.Mper, q = m - b * p.Mper;        // sample, pixel within the sample
+            int oy = q / p.Wout, ox = q - oy * p.Wout;
+            a_pix[i] = (b << 24) | (oy << 12) | ox;
         } else {
             a_pix[i] = m;
         }
@@ -419,10 +440,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             long off;
             if (CONV) {
-                int oy = a_pix[i] >> 16, ox = a_pix[i] & 0xffff;
+                int bb = a_pix[i] >> 24, oy = (a_pix[i] >> 12) & 0xfff, ox = a_pix[i] & 0xfff;
                 int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
                 bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                off = ok ? (long)(((size_t)(iy * p.Win + ix) * p.lda + c) * sizeof(float)) : zoff;
+                off = ok ? (long)(((size_t)((bb * p.Hin + iy) * p.Win + ix) * p.lda + c) * sizeof(float)) : zoff;
             } else {
                 off = kok ? (long)(((size_t)a_pix[i] * p.lda + k) * sizeof(float)) : zoff;
             }
@@ -469,13 +490,16 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-int launch_gemm(const GemmArgs& a, hipStream_t s) {
+int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    if (a.Mper <= 0) a.Mper = a.M;                       // single sample
+    UNI_REQUIRE(a.M % a.Mper == 0 && a.M / a.Mper < 128, "gemm: M=%d is not a multiple of Mper=%d", a.M, a.Mper);
     UNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     UNI_REQUIRE(a.K % (a.b32 ? 4 : 8) == 0 && a.Kpad % 64 == 0 && a.Kpad >= a.K, "gemm: K=%d Kpad=%d", a.K, a.Kpad);
     UNI_REQUIRE(a.lda % (a.b32 ? 4 : 8) == 0 && ((uintptr_t)a.A & 15) == 0, "gemm: lda=%d / A must be 16-byte aligned", a.lda);
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
     if (a.b32) {
-        if (conv) UNI_REQUIRE(a.Cin % 4 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 65536, "gemm(f32): conv K mismatch");
+        if (conv) UNI_REQUIRE(a.Cin % 4 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 4096 && a.Mper / a.Wout < 4096, "gemm(f32): conv K mismatch / map too large");
         if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
         const int grid = cdiv(a.M, 64) * cdiv(a.N, 64);
         const size_t lds = (size_t)2 * (64 + 64) * 32 * sizeof(float);
@@ -483,7 +507,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3(grid), dim3(256), lds, s, a);
         return 0;
     }
-    if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 65536, "gemm: conv K mismatch");
+    if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 4096 && a.Mper / a.Wout < 4096, "gemm: conv K mismatch / map too large");
     if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
     // tile choice (measured on MI355X, tools/gemm_bench.py): plain GEMMs want >= ~400 blocks of 128x64, implicit
     // convs amortise their gather address math over wider-N tiles

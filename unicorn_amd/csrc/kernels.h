@@ -9,6 +9,8 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, Kpad = 0;
     // conv geometry (1x1/s1/p0 => plain GEMM)
     int Hin = 0, Win = 0, Cin = 0, KH = 1, KW = 1, stride = 1, pad = 0, Wout = 0;
+    int Mper = 0;                             // output pixels per sample (M = B * Mper); GN stats slot b lives at stats + 64*b
+    int out_hw = 0, out_stride = 0, out_off = 0;   // optional outF row remap: (row/out_hw)*out_stride + out_off + row%out_hw
     // epilogue
     const float* bias = nullptr;              // [N]
     int act = ACT_NONE; int act_col0 = 0;     // activation on columns >= act_col0
@@ -42,7 +44,8 @@ struct GnApplyArgs {
     const float* x = nullptr; int ldx = 0;
     const double* stats = nullptr;            // [G][2] sum, sumsq
     const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-3f;
-    int M = 0, C = 0, G = 16, act = ACT_SILU;
+    int M = 0, C = 0, G = 16, act = ACT_SILU;    // M = rows PER SAMPLE
+    int B = 1;                                   // samples; x/out rows are [B*M], stats slot b at stats + 64*b
     const float* prior = nullptr; const float* prior_beta = nullptr;   // y += prior[m] * prior_beta[c]
     float* outF = nullptr; int ldf = 0;
     bf16* outB = nullptr; int ldb = 0;
@@ -57,7 +60,7 @@ struct DwLnArgs {
     const float* w = nullptr;                 // [49][C]
     const float* bias = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
     float eps = 1e-6f;
-    int H = 0, W = 0, C = 0;
+    int H = 0, W = 0, C = 0, B = 1;            // B images of (H,W,C) stacked
     bf16* out = nullptr;
     int b32 = 0;
 };
@@ -65,7 +68,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s);
 
 // stem: conv4x4/s4 (3->C) + bias + LN_cf: NCHW fp32 image -> fp32 NHWC
 struct StemArgs {
-    const float* img = nullptr; int H = 0, W = 0;   // (3,H,W)
+    const float* img = nullptr; int H = 0, W = 0, B = 1;   // (B,3,H,W)
     const float* w = nullptr;                       // [48][C]  (k = c*16 + ky*4 + kx)
     const float* bias = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
     int C = 0; float* out = nullptr;                // [H/4][W/4][C]
@@ -83,6 +86,7 @@ struct MsdaFusedArgs {
     int h = 0, w = 0;                         // both levels (h,w); Lq = 2*h*w
     bf16* out = nullptr;                      // [Lq][256]
     int b32 = 0;
+    int B = 1;                                // batch: tokens [B][2][hw]
 };
 int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s);
 
@@ -94,10 +98,10 @@ size_t corr_workspace_bytes(int R, int Q, int K);
 
 // ---------------------------------------------------------------- misc.hip
 int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32 = 0);
-int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32 = 0);
+int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32 = 0, int B = 1);
 int launch_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, hipStream_t s);
-int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s);
-int launch_add_aligned_bilinear(const float* src, int h, int w, int C, int factor, float* dst, hipStream_t s);
+int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s, int B = 1);
+int launch_add_aligned_bilinear(const float* src, int h, int w, int C, int factor, float* dst, hipStream_t s, int B = 1);
 int launch_pos_embed(const float* row, const float* col, int sz, int nf, float* out, int h, int w, hipStream_t s);
 int launch_sample_embed(const float* emb, int H, int W, int C, const float* boxes, int ldbox, int n, float stride,
                         float* out, hipStream_t s);
@@ -115,4 +119,4 @@ struct CondInstArgs {
 int launch_condinst(const CondInstArgs& a, hipStream_t s);
 int launch_label_map_s8(const float* box_xyxy, float* out, int H, int W, hipStream_t s);
 int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,
-                        int C, hipStream_t s, int b32 = 0);
+                        int C, hipStream_t s, int b32 = 0, int B = 1);

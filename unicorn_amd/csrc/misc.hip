@@ -23,23 +23,25 @@ int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, 
 }
 
 // PixelShuffle(2) + cast: fp32 NHWC (h,w,C) -> bf16 NHWC (2h,2w,C/4); in channel c*4+dy*2+dx -> out (2y+dy,2x+dx,c)
-__global__ void pixel_shuffle_kernel(const float* x, bf16* out, int h, int w, int C, int b32) {
+__global__ void pixel_shuffle_kernel(const float* x, bf16* out, int h, int w, int C, int b32, int B) {
     const int Co = C >> 2;
-    const long total = (long)4 * h * w * Co;
+    const long total = (long)4 * h * w * Co * B;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         int c = (int)(e % Co);
         long pix = e / Co;
-        int ox = (int)(pix % (2 * w)), oy = (int)(pix / (2 * w));
+        int ox = (int)(pix % (2 * w));
+        long oyg = pix / (2 * w);
+        int sb = (int)(oyg / (2 * h)), oy = (int)(oyg - (long)sb * 2 * h);
         int y = oy >> 1, xx = ox >> 1, dy = oy & 1, dx = ox & 1;
-        act_store1(out, (size_t)e, x[((size_t)y * w + xx) * C + c * 4 + dy * 2 + dx], b32);
+        act_store1(out, (size_t)e, x[(((size_t)sb * h + y) * w + xx) * C + c * 4 + dy * 2 + dx], b32);
     }
 }
-int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32) {
+int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32, int B) {
     UNI_REQUIRE(C % 4 == 0, "pixel_shuffle: C=%d", C);
-    long total = (long)h * w * C;
+    long total = (long)h * w * C * B;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid), dim3(256), 0, s, x, out, h, w, C, b32);
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid), dim3(256), 0, s, x, out, h, w, C, b32, B);
     return 0;
 }
 
@@ -68,24 +70,26 @@ int launch_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8,
 }
 
 // unicorn_head.py:467-482: xy = (xy + grid) * stride, wh = exp(wh) * stride; in place on (A, nch) rows
-__global__ void decode_kernel(float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= A0 + A1 + A2) return;
+__global__ void decode_kernel(float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, int B) {
+    const int ag = blockIdx.x * blockDim.x + threadIdx.x;
+    const int A = A0 + A1 + A2;
+    if (ag >= A * B) return;
+    const int a = ag % A;
     int loc, W;
     float st;
     if (a < A0) { loc = a; W = W0; st = 8.f; }
     else if (a < A0 + A1) { loc = a - A0; W = W1; st = 16.f; }
     else { loc = a - A0 - A1; W = W2; st = 32.f; }
     const int gy = loc / W, gx = loc - gy * W;
-    float* o = out + (size_t)a * nch;
+    float* o = out + (size_t)ag * nch;
     o[0] = (o[0] + gx) * st;
     o[1] = (o[1] + gy) * st;
     o[2] = expf(o[2]) * st;
     o[3] = expf(o[3]) * st;
 }
-int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s) {
+int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s, int B) {
     UNI_REQUIRE(raw == out, "decode: in-place only");
-    hipLaunchKernelGGL(decode_kernel, dim3(cdiv(A0 + A1 + A2, 256)), dim3(256), 0, s, out, A0, W0, A1, W1, A2, W2, nch);
+    hipLaunchKernelGGL(decode_kernel, dim3(cdiv((A0 + A1 + A2) * B, 256)), dim3(256), 0, s, out, A0, W0, A1, W1, A2, W2, nch, B);
     return 0;
 }
 
@@ -102,6 +106,8 @@ __device__ __forceinline__ void ab_coord(int o, int f, int n, int& i0, int& i1, 
 __global__ void add_aligned_bilinear_kernel(const float* src, int h, int w, int C, int f, float* dst) {
     const int H = f * h, W = f * w, C4 = C >> 2;
     const long total = (long)H * W * C4;
+    src += (size_t)blockIdx.y * h * w * C;                       // sample of the batch
+    dst += (size_t)blockIdx.y * H * W * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         int c = (int)(e % C4) * 4;
         long pix = e / C4;
@@ -124,12 +130,12 @@ __global__ void add_aligned_bilinear_kernel(const float* src, int h, int w, int 
         *o = v;
     }
 }
-int launch_add_aligned_bilinear(const float* src, int h, int w, int C, int factor, float* dst, hipStream_t s) {
+int launch_add_aligned_bilinear(const float* src, int h, int w, int C, int factor, float* dst, hipStream_t s, int B) {
     UNI_REQUIRE(C % 4 == 0 && factor >= 1, "aligned_bilinear: C=%d factor=%d", C, factor);
     long total = (long)factor * h * factor * w * (C / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(add_aligned_bilinear_kernel, dim3(grid), dim3(256), 0, s, src, h, w, C, factor, dst);
+    hipLaunchKernelGGL(add_aligned_bilinear_kernel, dim3(grid, B), dim3(256), 0, s, src, h, w, C, factor, dst);
     return 0;
 }
 
@@ -326,25 +332,25 @@ int launch_condinst(const CondInstArgs& a, hipStream_t s) {
 
 // deformable_transformer.py:74,124: query = src + pos + level_embed[lvl] (bf16 operand of the offset/weight Linears)
 __global__ void add_pos_kernel(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out,
-                               int hw, int C, int b32) {
+                               int hw, int C, int b32, int B) {
     const int C4 = C >> 2;
-    const long total = (long)2 * hw * C4;
+    const long total = (long)2 * hw * C4 * B;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         int c = (int)(e % C4) * 4;
-        int m = (int)(e / C4);
-        int l = m >= hw;
-        const float* pos = l ? pos1 : pos0;
+        int m = (int)(e / C4);                                   // token over [B][2 frames][hw]
+        int l = (m / hw) & 1;
+        const float* pos = l ? pos1 : pos0;                      // position embedding is shared by the batch
         float4 a = *reinterpret_cast<const float4*>(src + (size_t)m * C + c);
-        float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(m - l * hw) * C + c);
+        float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(m % hw) * C + c);
         float4 d = *reinterpret_cast<const float4*>(lvl + l * C + c);
         act_store4(out, (size_t)m * C + c, a.x + (b.x + d.x), a.y + (b.y + d.y), a.z + (b.z + d.z), a.w + (b.w + d.w), b32);
     }
 }
 int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,
-                        int C, hipStream_t s, int b32) {
-    long total = (long)2 * hw * (C / 4);
+                        int C, hipStream_t s, int b32, int B) {
+    long total = (long)2 * hw * (C / 4) * B;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, s, src, pos0, pos1, lvl, out, hw, C, b32);
+    hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, s, src, pos0, pos1, lvl, out, hw, C, b32, B);
     return 0;
 }

@@ -72,9 +72,11 @@ int launch_msda(const float* value, const int64_t* shapes, const int64_t* lsi, c
 __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs p) {
     const int hw = p.h * p.w, Lq = 2 * hw;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)Lq * 256) return;
-    const int d = idx & 31, m = (idx >> 5) & 7, q = (int)(idx >> 8);
-    const float* row = p.offaw + (size_t)q * p.ldo;
+    if (idx >= (long)Lq * 256 * p.B) return;
+    const int d = idx & 31, m = (idx >> 5) & 7;
+    const int qg = (int)(idx >> 8);                              // token over [B][2 frames][hw]
+    const int sb = qg / Lq, q = qg - sb * Lq;
+    const float* row = p.offaw + (size_t)qg * p.ldo;
     const float* off = row + m * 16;
     const float* lg = row + 128 + m * 8;
     float w8[8], mx = -3.0e38f, sum = 0.f;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs p) {
     float acc = 0.f;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        const float* vb = p.value + (size_t)l * hw * 256 + m * 32 + d;
+        const float* vb = p.value + ((size_t)sb * Lq + (size_t)l * hw) * 256 + m * 32 + d;
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
             const float lx = refx + off[(l * 4 + pt) * 2] / p.w;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs p) {
 }
 
 int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s) {
-    const long total = (long)2 * a.h * a.w * 256;
+    const long total = (long)2 * a.h * a.w * 256 * a.B;
     hipLaunchKernelGGL(msda_fused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return 0;
 }

@@ -89,11 +89,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     float* scale = sm;
     float* shift = sm + p.C;
     const int cpg = p.C / p.G;
+    const int sb = blockIdx.y;                                   // sample of the batch; M = rows PER SAMPLE
+    const double* st = p.stats + (size_t)sb * 64;
     const double cnt = (double)p.M * cpg;
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
         int g = c / cpg;
-        double mean = p.stats[2 * g] / cnt;
-        double var = p.stats[2 * g + 1] / cnt - mean * mean;
+        double mean = st[2 * g] / cnt;
+        double var = st[2 * g + 1] / cnt - mean * mean;
         float rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)p.eps));
         float ga = p.gamma[c] * rstd;
         scale[c] = ga;
@@ -102,9 +104,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     __syncthreads();
     const int C8 = p.C >> 3;
     const long total = (long)p.M * C8;
+    const size_t row0 = (size_t)sb * p.M;                        // first global row of this sample
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        int m = (int)(e / C8);
-        int c = (int)(e - (long)m * C8) * 8;
+        const int ml = (int)(e / C8);                            // row within the sample
+        const size_t m = row0 + ml;
+        int c = (int)(e - (long)ml * C8) * 8;
         const float4* xp = reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + c);
         float4 a = xp[0], b = xp[1];
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -122,9 +126,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
         }
         if (p.outB) act_store8(p.outB, (size_t)m * p.ldb + c, v, p.b32);
         if (p.outUp) {
-            int y = m / p.W, x = m - y * p.W;
+            int y = ml / p.W, x = ml - y * p.W;
             size_t W2 = 2 * (size_t)p.W;
-            size_t u = ((size_t)(2 * y) * W2 + 2 * x) * p.ldu + c;
+            size_t u = (4 * row0 + (size_t)(2 * y) * W2 + 2 * x) * p.ldu + c;
             act_store8(p.outUp, u, v, p.b32);
             act_store8(p.outUp, u + p.ldu, v, p.b32);
             act_store8(p.outUp, u + W2 * p.ldu, v, p.b32);
@@ -140,7 +144,7 @@ int launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     long total = (long)a.M * (a.C / 8);
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 2 * a.C * sizeof(float), s, a);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid, a.B > 0 ? a.B : 1), dim3(256), 2 * a.C * sizeof(float), s, a);
     return 0;
 }
 
@@ -195,9 +199,9 @@ static size_t strip_reduce_lds(int S, int CG, int NV) {
 // maps (2x the waves: the stride-16/32 maps are latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------------------
 template <int IN>
-__device__ __forceinline__ void dw_load_row(f32x4 (&dst)[IN], const DwLnArgs& p, int iy, int x0, int cg) {
+__device__ __forceinline__ void dw_load_row(f32x4 (&dst)[IN], const DwLnArgs& p, size_t img0, int iy, int x0, int cg) {
     const bool rok = iy >= 0 && iy < p.H;
-    const float* rowp = p.x + ((size_t)(rok ? iy : 0) * p.W) * p.C + cg * 4;
+    const float* rowp = p.x + (img0 + (size_t)(rok ? iy : 0) * p.W) * p.C + cg * 4;
 #pragma unroll
     for (int j = 0; j < IN; ++j) {
         int ix = x0 + j - 3;
@@ -222,8 +226,10 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
     }
     const int strip = blk * S + sl;
     const bool active = sl < S && strip < nstrips;
-    const int y = active ? strip / spr : 0;
-    const int x0 = active ? (strip - y * spr) * PX : 0;
+    const int yg = active ? strip / spr : 0;                    // row over the whole batch
+    const int x0 = active ? (strip - yg * spr) * PX : 0;
+    const int sb = yg / p.H, y = yg - sb * p.H;                  // sample, row within the sample
+    const size_t img0 = (size_t)sb * p.H * p.W;                  // first pixel of this sample
     const int C = p.C;
     f32x4 acc[PX];
     {
@@ -233,10 +239,10 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
     }
     if (active) {
         f32x4 cur[IN], nxt[IN];
-        dw_load_row<IN>(cur, p, y - 3, x0, cg);
+        dw_load_row<IN>(cur, p, img0, y - 3, x0, cg);
 #pragma unroll 1
         for (int ky = 0; ky < 7; ++ky) {
-            if (ky < 6) dw_load_row<IN>(nxt, p, y + ky - 2, x0, cg);      // prefetch the next input row
+            if (ky < 6) dw_load_row<IN>(nxt, p, img0, y + ky - 2, x0, cg);      // prefetch the next input row
             const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
     for (int o = 0; o < PX; ++o) {
         if (x0 + o < p.W) {
             float rstd = 1.f / sqrtf(tot[o] / C + p.eps);
-            act_store4(p.out, ((size_t)y * p.W + x0 + o) * C + cg * 4, (acc[o][0] - mean[o]) * rstd * g[0] + be[0],
+            act_store4(p.out, (img0 + (size_t)y * p.W + x0 + o) * C + cg * 4, (acc[o][0] - mean[o]) * rstd * g[0] + be[0],
                        (acc[o][1] - mean[o]) * rstd * g[1] + be[1], (acc[o][2] - mean[o]) * rstd * g[2] + be[2],
                        (acc[o][3] - mean[o]) * rstd * g[3] + be[3], p.b32);
         }
@@ -285,13 +291,14 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     const int T = cdiv(S * CG, 64) * 64;
     // PX = 8 only when the 8-pixel strips alone already give >= 8 waves per SIMD
     static const char* env = getenv("UNI_DW_PX");
-    int px = ((long)cdiv(a.W, 8) * a.H * CG >= 300000L) ? 8 : 4;   // measured crossover (tools/norm_bench.py)
+    const int nb = a.B > 0 ? a.B : 1;
+    int px = ((long)cdiv(a.W, 8) * a.H * nb * CG >= 300000L) ? 8 : 4;   // measured crossover (tools/norm_bench.py)
     if (env) px = atoi(env);
     if (px == 8) {
-        const int spr = cdiv(a.W, 8), nstrips = spr * a.H;
+        const int spr = cdiv(a.W, 8), nstrips = spr * a.H * nb;
         hipLaunchKernelGGL(dwconv7_ln_kernel<8>, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 8), s, a, S, CG, spr, nstrips);
     } else {
-        const int spr = cdiv(a.W, 4), nstrips = spr * a.H;
+        const int spr = cdiv(a.W, 4), nstrips = spr * a.H * nb;
         hipLaunchKernelGGL(dwconv7_ln_kernel<4>, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 4), s, a, S, CG, spr, nstrips);
     }
     return 0;
@@ -315,9 +322,11 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs p, int S, int CG, in
         int px = blockIdx.x * S + sp;
         float v = 0.f;
         if (px < npix) {
-            int oy = px / Wo, ox = px - oy * Wo;
+            const int per = (p.H >> 2) * Wo;
+            int sb = px / per, q = px - sb * per;
+            int oy = q / Wo, ox = q - oy * Wo;
             int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
-            v = p.img[((size_t)c * p.H + oy * 4 + ky) * p.W + ox * 4 + kx];
+            v = p.img[(((size_t)sb * 3 + c) * p.H + oy * 4 + ky) * p.W + ox * 4 + kx];
         }
         patch[u] = v;
     }
@@ -353,7 +362,7 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
     const int CG = a.C / 4;
     int S = 256 / CG;
     if (S < 1) S = 1;
-    const int npix = (a.H / 4) * (a.W / 4);
+    const int npix = (a.H / 4) * (a.W / 4) * (a.B > 0 ? a.B : 1);
     const int T = cdiv(S * CG, 64) * 64;
     size_t lds = S * 48 * sizeof(float) + strip_reduce_lds(S, CG, 1);
     hipLaunchKernelGGL(stem_kernel, dim3(cdiv(npix, S)), dim3(T), lds, s, a, S, CG, npix);

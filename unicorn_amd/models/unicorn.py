@@ -68,23 +68,24 @@ class UnicornHead:
         m = self._m
         m._require_ready()
         f = [nhwc(x) for x in xin]
+        B = f[0].shape[0]
         H, W = f[0].shape[2] * 8, f[0].shape[3] * 8
         pri = []
         for k, p in enumerate(mask_in):
-            if p.shape[1] != 1 or p.shape[0] != 1:
-                raise ValueError("head: priors must be (1,1,H/s,W/s); run one object per call like the reference drivers")
+            if p.shape[1] != 1 or p.shape[0] != B:
+                raise ValueError("head: priors must be (B,1,H/s,W/s); run one object per call like the reference drivers")
             pri.append(p.float().contiguous())
         nc = 1 if mode == "sot" else self.num_classes
         A = sum(x.shape[2] * x.shape[3] for x in f)
         dev = f[0].device
-        out = torch.empty((1, A, 5 + nc), device=dev, dtype=torch.float32)
+        out = torch.empty((B, A, 5 + nc), device=dev, dtype=torch.float32)
         dyn = mf = um = None
         if m.mask:
-            dyn = torch.empty((1, A, 169), device=dev, dtype=torch.float32)
-            mf = empty_nhwc(8, H // 8, W // 8, dev)
-            um = empty_nhwc(9 * m.up_rate ** 2, H // 8, W // 8, dev)
+            dyn = torch.empty((B, A, 169), device=dev, dtype=torch.float32)
+            mf = empty_nhwc(8, H // 8, W // 8, dev, B)
+            um = empty_nhwc(9 * m.up_rate ** 2, H // 8, W // 8, dev, B)
         L.check(L.lib().uni_head(m._ctx, L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(pri[0]), L.ptr(pri[1]), L.ptr(pri[2]),
-                                 H, W, 0 if mode == "sot" else 1, L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
+                                 B, H, W, 0 if mode == "sot" else 1, L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
                                  L.stream_ptr()), "uni_head")
         self.hw = [tuple(x.shape[2:]) for x in f]
         return out, dyn, mf, um
@@ -111,7 +112,7 @@ class UnicornHeadMask(UnicornHead):
         out, dyn, mf, um = self._run(xin, mask_in, mode)
         grids, strides = self._m._grids(self.hw, out.device)
         locations = ((grids + 0.5) * strides)[0]                               # unicorn_head_mask.py:518
-        levels = torch.cat([torch.full((1, h * w), k) for k, (h, w) in enumerate(self.hw)], 1)   # CPU like the reference
+        levels = torch.cat([torch.full((out.shape[0], h * w), k) for k, (h, w) in enumerate(self.hw)], 1)   # CPU like the reference
         return out, locations, dyn, levels, mf, um
 
 
@@ -268,39 +269,43 @@ class Unicorn:
     def forward_backbone(self, img, run_fpn=True):
         assert isinstance(img, torch.Tensor)
         self._require_ready()
-        if img.dim() != 4 or img.shape[0] != 1 or img.shape[1] != 3:
-            raise ValueError("forward_backbone expects a (1,3,H,W) image batch (drivers run -b 1)")
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise ValueError("forward_backbone expects a (B,3,H,W) image batch")
         if not img.is_cuda:
             raise L.UnicornHipError("input image must be a HIP device tensor; no CPU fallback")
         x = img.float().contiguous()
-        _, _, H, W = x.shape
+        B, _, H, W = x.shape
         dev = x.device
         c1, c2, c3 = self.dims[1:]
-        fpn = (empty_nhwc(c1, H // 8, W // 8, dev), empty_nhwc(c2, H // 16, W // 16, dev), empty_nhwc(c3, H // 32, W // 32, dev))
-        feat16 = empty_nhwc(c2, H // 16, W // 16, dev)
-        L.check(L.lib().uni_backbone_fpn(self._ctx, L.ptr(x), H, W, L.ptr(fpn[0]), L.ptr(fpn[1]), L.ptr(fpn[2]), L.ptr(feat16),
+        fpn = (empty_nhwc(c1, H // 8, W // 8, dev, B), empty_nhwc(c2, H // 16, W // 16, dev, B), empty_nhwc(c3, H // 32, W // 32, dev, B))
+        feat16 = empty_nhwc(c2, H // 16, W // 16, dev, B)
+        L.check(L.lib().uni_backbone_fpn(self._ctx, L.ptr(x), B, H, W, L.ptr(fpn[0]), L.ptr(fpn[1]), L.ptr(fpn[2]), L.ptr(feat16),
                                          L.stream_ptr()), "uni_backbone_fpn")
         h, w = H // 16, W // 16
-        seq_dict = {"feat": feat16, "pos": self._pos(h, w), "h": h, "w": w}
+        seq_dict = {"feat": feat16, "pos": self._pos(h, w).expand(B, -1, -1, -1), "h": h, "w": w}
         return (fpn, seq_dict) if run_fpn else seq_dict
 
     def forward_deform_interact(self, d0, d1):
         self._require_ready()
-        f0, f1, p0, p1 = nhwc(d0["feat"]), nhwc(d1["feat"]), nhwc(d0["pos"]), nhwc(d1["pos"])
+        f0, f1 = nhwc(d0["feat"]), nhwc(d1["feat"])
+        p0, p1 = nhwc(d0["pos"][0:1]), nhwc(d1["pos"][0:1])      # the learned position embedding is batch-invariant
         h, w = d0["h"], d0["w"]
+        B = f1.shape[0]
+        if f0.shape[0] == 1 and B > 1:                             # one reference frame for a batch of current frames
+            f0 = nhwc(f0.expand(B, -1, -1, -1))
         if tuple(f1.shape) != tuple(f0.shape):
             raise ValueError("interaction: reference and current feature maps must have the same shape")
-        o0, o1 = empty_nhwc(256, h, w, f0.device), empty_nhwc(256, h, w, f0.device)
-        L.check(L.lib().uni_interaction(self._ctx, L.ptr(f0), L.ptr(p0), L.ptr(f1), L.ptr(p1), h, w, L.ptr(o0), L.ptr(o1),
+        o0, o1 = empty_nhwc(256, h, w, f0.device, B), empty_nhwc(256, h, w, f0.device, B)
+        L.check(L.lib().uni_interaction(self._ctx, L.ptr(f0), L.ptr(p0), L.ptr(f1), L.ptr(p1), B, h, w, L.ptr(o0), L.ptr(o1),
                                         L.stream_ptr()), "uni_interaction")
         return o0, o1
 
     def forward_upsample(self, x):
         self._require_ready()
         f = nhwc(x)
-        _, c, h, w = f.shape
+        B, c, h, w = f.shape
         if c != 256:
             raise ValueError("upsample expects a 256-channel map")
-        e = empty_nhwc(self.embed_dim, 2 * h, 2 * w, f.device)
-        L.check(L.lib().uni_upsample(self._ctx, L.ptr(f), h, w, L.ptr(e), L.stream_ptr()), "uni_upsample")
+        e = empty_nhwc(self.embed_dim, 2 * h, 2 * w, f.device, B)
+        L.check(L.lib().uni_upsample(self._ctx, L.ptr(f), B, h, w, L.ptr(e), L.stream_ptr()), "uni_upsample")
         return e

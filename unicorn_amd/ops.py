@@ -18,8 +18,8 @@ def nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-def empty_nhwc(c, h, w, device):
-    return torch.empty((1, c, h, w), device=device, dtype=torch.float32, memory_format=torch.channels_last)
+def empty_nhwc(c, h, w, device, b=1):
+    return torch.empty((b, c, h, w), device=device, dtype=torch.float32, memory_format=torch.channels_last)
 
 
 def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step=64):
