@@ -126,7 +126,7 @@ int uni_condinst_masks(const float* mask_feats, const float* up_masks, const flo
 
 /* ---- low-level building blocks (exported for kernel parity tests) --------------------------------------- */
 /* out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+res).  A: bf16 NHWC map (Hin,Win,Cin) row stride lda.
- * w_packed: [roundup(N,128)][roundup(K,64)] bf16, K order (ky,kx,c) (see uni_pack_weight). */
+ * w_packed: [roundup(N,256)][roundup(K,64)] bf16, K order (ky,kx,c) (see uni_pack_weight). */
 int uni_pack_weight(const float* w_oihw_host, int N, int Cin, int KH, int KW, uint16_t* out_host_bf16);
 int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, int N, int Hin, int Win, int Cin, int KH,
                   int KW, int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF,

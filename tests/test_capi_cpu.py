@@ -33,7 +33,7 @@ def test_pack_weight_matches_numpy():
     lib = _lib.lib()
     g = torch.Generator().manual_seed(0)
     w = torch.randn(5, 16, 3, 3, generator=g)
-    out = np.zeros((128, 192), dtype=np.uint16)
+    out = np.zeros((256, 192), dtype=np.uint16)
     wc = np.ascontiguousarray(w.numpy())
     assert lib.uni_pack_weight(wc.ctypes.data_as(C.c_void_p), 5, 16, 3, 3, out.ctypes.data_as(C.c_void_p)) == 0
     exp = w.permute(0, 2, 3, 1).reshape(5, 144).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)

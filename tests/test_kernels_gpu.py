@@ -38,7 +38,7 @@ def as_u16(t):
 def pack_weight(L, w):
     N, Cin, KH, KW = w.shape
     K = Cin * KH * KW
-    Npad, Kpad = (N + 127) // 128 * 128, (K + 63) // 64 * 64
+    Npad, Kpad = (N + 255) // 256 * 256, (K + 63) // 64 * 64
     out = np.zeros((Npad, Kpad), dtype=np.uint16)
     wc = np.ascontiguousarray(w.float().numpy())
     L.check(L.lib().uni_pack_weight(wc.ctypes.data_as(C.c_void_p), N, Cin, KH, KW, out.ctypes.data_as(C.c_void_p)), "pack")
@@ -48,7 +48,7 @@ def pack_weight(L, w):
 ACTS = {0: lambda x: x, 1: F.relu, 2: F.gelu, 3: F.silu, 4: torch.sigmoid}
 
 
-@pytest.mark.parametrize("cfg", [0, 22, 12, 21, 11, 122, 142])
+@pytest.mark.parametrize("cfg", [0, 22, 12, 21, 11, 122, 42, 24, 44])
 @pytest.mark.parametrize("case", [
     # (Hin, Win, Cin, N, KH, stride, pad, act, bias, res, stats_G)
     (20, 24, 96, 384, 1, 1, 0, 2, True, False, 0),        # tiny pwconv1 + GELU, K=96 (padded to 128)

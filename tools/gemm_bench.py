@@ -20,6 +20,9 @@ SHAPES = [
     ("up1", 100, 160, 64, 256, 3, 1), ("up3", 100, 160, 256, 128, 3, 1),
     ("T.s0.pw1", 64000, 1, 96, 384, 1, 1), ("T.s2.pw1", 4000, 1, 384, 1536, 1, 1),
 ]
+import os as _os
+SCALE = int(_os.environ.get("GEMM_SCALE", "1"))     # multiply M (emulates a batch of frames)
+SHAPES = [(n, h * SCALE, w, c, nn, k, st) for (n, h, w, c, nn, k, st) in SHAPES]
 cfgs = [int(a) for a in sys.argv[1:]] or [22, 21, 12, 11]
 print("%-18s %8s %6s %6s | " % ("shape", "M", "N", "K") + " ".join("%9s" % ("cfg%d" % c) for c in cfgs))
 for name, Hin, Win, Cin, N, k, stride in SHAPES:
@@ -27,7 +30,7 @@ for name, Hin, Win, Cin, N, k, stride in SHAPES:
     Hout, Wout = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
     M, K = Hout * Wout, Cin * k * k
     A = (torch.randn(Hin * Win, Cin, device="cuda")).to(torch.bfloat16)
-    Npad, Kpad = (N + 127) // 128 * 128, (K + 63) // 64 * 64
+    Npad, Kpad = (N + 255) // 256 * 256, (K + 63) // 64 * 64
     Wp = (torch.randn(Npad, Kpad, device="cuda") * 0.05).to(torch.bfloat16)
     outB = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     res = []

@@ -9,7 +9,7 @@ pad = (k - 1) // 2
 Hout, Wout = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
 M, K = Hout * Wout, Cin * k * k
 A = torch.randn(Hin * Win, Cin, device="cuda").to(torch.bfloat16)
-Npad, Kpad = (N + 127) // 128 * 128, (K + 63) // 64 * 64
+Npad, Kpad = (N + 255) // 256 * 256, (K + 63) // 64 * 64
 Wp = (torch.randn(Npad, Kpad, device="cuda") * 0.05).to(torch.bfloat16)
 outB = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
 for _ in range(reps):

@@ -141,7 +141,7 @@ int uni_condinst_masks(const float* mask_feats, const float* up_masks, const flo
 
 int uni_pack_weight(const float* w, int N, int Cin, int KH, int KW, uint16_t* out) {
     UNI_REQUIRE(w && out && N > 0 && Cin > 0, "pack_weight: bad argument");
-    pack_weight_host(w, N, Cin, KH, KW, nullptr, out, cdiv(N, 128) * 128, cdiv(Cin * KH * KW, 64) * 64);
+    pack_weight_host(w, N, Cin, KH, KW, nullptr, out, cdiv(N, 256) * 256, cdiv(Cin * KH * KW, 64) * 64);
     return 0;
 }
 int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, int N, int Hin, int Win, int Cin, int KH, int KW,

@@ -85,7 +85,7 @@ static PConv pack_convs(uni_ctx* c, const std::vector<ConvSrc>& srcs, int Cin, i
     bool any_bias = false;
     for (auto& s : srcs) { N += s.N; any_bias |= !s.b.empty(); }
     p.N = N;
-    const int Npad = cdiv(N, 128) * 128;
+    const int Npad = cdiv(N, 256) * 256;   // widest block tile is 256 output channels
     std::vector<uint16_t> packed((size_t)Npad * p.Kpad, 0);
     std::vector<float> bias(N, 0.f);
     int n0 = 0;

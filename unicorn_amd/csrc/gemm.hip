@@ -23,6 +23,7 @@
 //    the 32 pixel lanes -> LDS -> one double atomic per group per block).
 //  * Blocks are remapped so each XCD (private 4 MiB L2) owns a contiguous range of M panels.
 #include "kernels.h"
+#include <cstdlib>
 
 __device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
 
@@ -39,10 +40,10 @@ __device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
 
 // ---- shared epilogue: lane owns pixel row = m0 + wm*32*TM + i*32 + (lane&31) and, per accumulator quad g,
 // channels n0 + wn*32*TN + j*32 + 8g + 4*(lane>>5) + {0,1,2,3} ----
-template <int TM, int TN, bool STATS>
+template <int WM, int WN, int TM, int TN, bool STATS>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int lane, int tid, char* smem) {
-    constexpr int BN = 64 * TN;
+    constexpr int BN = 32 * TN * WN, BMt = 32 * TM * WM;
     const int fr = lane & 31, fh = lane >> 5;
     const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
@@ -140,10 +141,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
         // reduction runs once per sample present in the tile (one iteration except at sample boundaries).
         // Pixel lanes are reduced with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps register index
         // r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
-        float* red = reinterpret_cast<float*>(smem);          // [2 wm][BN][2]
-        float* gacc = red + 2 * BN * 2;                       // [64][2]
+        float* red = reinterpret_cast<float*>(smem);          // [WM][BN][2]
+        float* gacc = red + WM * BN * 2;                      // [64][2]
         const int b_lo = m0 / p.Mper;
-        const int b_hi = min(p.M - 1, m0 + 64 * TM - 1) / p.Mper;
+        const int b_hi = min(p.M - 1, m0 + BMt - 1) / p.Mper;
         for (int sb = b_lo; sb <= b_hi; ++sb) {
             const int r_lo = sb * p.Mper, r_hi = min(r_lo + p.Mper, p.M);
             float gs[TN][16], gq[TN][16];
@@ -224,8 +225,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             __syncthreads();
             const int g_first = n0 / p.cpg;
             if (tid < BN && n0 + tid < p.N) {
-                float s = red[tid * 2] + red[(BN + tid) * 2];
-                float q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < WM; ++w_) { s += red[(w_ * BN + tid) * 2]; q += red[(w_ * BN + tid) * 2 + 1]; }
                 int gl = (n0 + tid) / p.cpg - g_first;
                 atomicAdd(&gacc[gl * 2], s);
                 atomicAdd(&gacc[gl * 2 + 1], q);
@@ -238,14 +240,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     }
 }
 
-template <int TM, int TN, int BK, bool CONV, bool STATS>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, bool STATS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int NW = WM * WN;                                  // waves per block, arranged WM (pixels) x WN (channels)
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int CPR = BK / 8;             // 16-B chunks per LDS row (row = BK bf16 = 128 B or 64 B)
     constexpr int RPP = 64 / CPR;           // rows per 1-KiB DMA piece (8 or 16)
     constexpr int SW = BK == 64 ? 1 : 2;    // swizzle: chunk' = chunk ^ ((row >> SW) & (CPR-1))  (256-B bank period)
-    constexpr int A_PC = BM / RPP / 4;      // 1-KiB pieces per wave for the A tile
-    constexpr int B_PC = BN / RPP / 4;
+    constexpr int A_PC = BM / RPP / NW;     // 1-KiB pieces per wave for the A tile
+    constexpr int B_PC = BN / RPP / NW;
+    static_assert(A_PC >= 1 && B_PC >= 1 && NW % 2 == 0, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*BK]
     bf16* Bs = As + 2 * BM * BK;                              // [2][BN*BK]
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware bijective block remap (block b runs on XCD b%8) ----
     const int nbn = (p.N + BN - 1) / BN;
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int m0 = bm * BM, n0 = bn * BN;
 
     // ---- per-lane DMA source descriptors ----
-    // piece pc = wave + 4*i covers tile rows RPP*pc .. RPP*pc+RPP-1; lane -> row RPP*pc + lane/CPR, physical chunk
+    // piece pc = wave + NW*i covers tile rows RPP*pc .. RPP*pc+RPP-1; lane -> row RPP*pc + lane/CPR, physical chunk
     // lane%CPR; logical chunk = physical ^ swizzle(row), which is independent of i for both BK (see header).
     const int lrow = lane / CPR;
     const int lch = (lane % CPR) ^ (((RPP * wave + lrow) >> SW) & (CPR - 1));
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     int a_pix[A_PC];
 #pragma unroll
     for (int i = 0; i < A_PC; ++i) {
-        int m = m0 + RPP * (wave + 4 * i) + lrow;
+        int m = m0 + RPP * (wave + NW * i) + lrow;
         m = m < p.M ? m : p.M - 1;
         if (CONV) {
             int b = m / p.Mper, q = m - b * p.Mper;        // sample, pixel within the sample
@@ -316,18 +320,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                 bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
                 long off = ok ? (long)(((size_t)((bb * p.Hin + iy) * p.Win + ix) * p.lda + c) * sizeof(bf16)) : zoff;
                 OPAQUE64(off);   // keep ONE DMA per piece (hipcc otherwise splits the select into exec-masked branches)
-                GLDS16(abase + off, adst + i * 4096);
+                GLDS16(abase + off, adst + i * NW * 1024);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < A_PC; ++i) {
                 long off = kok ? (long)(((size_t)a_pix[i] * p.lda + k) * sizeof(bf16)) : zoff;
                 OPAQUE64(off);
-                GLDS16(abase + off, adst + i * 4096);
+                GLDS16(abase + off, adst + i * NW * 1024);
             }
         }
 #pragma unroll
-        for (int i = 0; i < B_PC; ++i) GLDS16(wbase + (size_t)i * 4 * RPP * p.Kpad + kt * BK, bdst + i * 4096);
+        for (int i = 0; i < B_PC; ++i) GLDS16(wbase + (size_t)i * NW * RPP * p.Kpad + kt * BK, bdst + i * NW * 1024);
     };
 
     f32x16 acc[TM][TN];
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         }
     }
 
-    gemm_epilogue<TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+    gemm_epilogue<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -475,18 +479,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], fa[e], acc[0][0], 0, 0, 0);
         }
     }
-    if (p.stats) gemm_epilogue<1, 1, true>(p, acc, m0, n0, wm, wn, lane, tid, smem);
-    else gemm_epilogue<1, 1, false>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+    if (p.stats) gemm_epilogue<2, 2, 1, 1, true>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+    else gemm_epilogue<2, 2, 1, 1, false>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
-template <int TM, int TN, int BK, bool CONV>
+template <int WM, int WN, int TM, int TN, int BK, bool CONV>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
-    if (lds < (2 * BN * 2 + 128) * sizeof(float)) lds = (2 * BN * 2 + 128) * sizeof(float);
-    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, BK, CONV, true>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, BK, CONV, false>), dim3(grid), dim3(256), lds, s, a);
+    if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
+    static bool attr_done = false;      // > 64 KiB dynamic LDS needs the opt-in attribute
+    if (!attr_done && lds > 65536) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return 0;
 }
 
@@ -509,28 +519,33 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     }
     if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 4096 && a.Mper / a.Wout < 4096, "gemm: conv K mismatch / map too large");
     if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
-    // tile choice (measured on MI355X, tools/gemm_bench.py): plain GEMMs want >= ~400 blocks of 128x64, implicit
-    // convs amortise their gather address math over wider-N tiles
+    // tile choice (measured on MI355X, tools/gemm_bench.py at batch-1 and batch-8 row counts): the K loop is bound by
+    // the global->LDS fill rate, so the biggest block tile that still yields >= ~1.5 blocks per CU wins (256x256,
+    // 16 waves); small problems want >= ~400 blocks of a smaller tile; implicit convs amortise their gather
+    // address math over wider-N tiles.
+    const long b44 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     const long b22 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b21 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
     const long b12 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
+    const double util44 = (double)a.N / (cdiv(a.N, 256) * 256.0);
     int cfg = a.force_cfg % 1000;
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
+        else if (util44 >= 0.74 && (b44 >= 1500 || (b44 >= 384 && a.K >= 512)) && !getenv("UNI_NO44")) cfg = 44;
+        else if (b22 >= 512) cfg = 22;
         else if (conv) cfg = b22 >= 400 ? 22 : (b12 >= 400 ? 12 : 11);
-        else cfg = b22 >= 2048 ? 22 : (b21 >= 400 ? 21 : 11);
+        else cfg = b21 >= 400 ? 21 : 11;
     }
-#define GO(TM, TN, BK) return conv ? launch_cfg<TM, TN, BK, true>(a, s) : launch_cfg<TM, TN, BK, false>(a, s)
-    switch (cfg) {   // code = [1 if BK == 32] TM TN
-        case 142: GO(4, 2, 32);
-        case 124: GO(2, 4, 32);
-        case 122: GO(2, 2, 32);
-        case 112: GO(1, 2, 32);
-        case 121: GO(2, 1, 32);
-        case 22: GO(2, 2, 64);
-        case 12: GO(1, 2, 64);
-        case 21: GO(2, 1, 64);
-        default: GO(1, 1, 64);
+#define GO(WM, WN, TM, TN, BK) return conv ? launch_cfg<WM, WN, TM, TN, BK, true>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false>(a, s)
+    switch (cfg) {   // 2-digit codes: 4 waves (2x2), wave tile 32TM x 32TN; 44 / 42 / 24: 16 / 8 / 8 waves of 64x64 wave tiles
+        case 44: GO(4, 4, 2, 2, 64);     // 256 x 256 block tile, 128 KiB LDS
+        case 42: GO(4, 2, 2, 2, 64);     // 256 x 128
+        case 24: GO(2, 4, 2, 2, 64);     // 128 x 256
+        case 122: GO(2, 2, 2, 2, 32);
+        case 22: GO(2, 2, 2, 2, 64);
+        case 12: GO(2, 2, 1, 2, 64);
+        case 21: GO(2, 2, 2, 1, 64);
+        default: GO(2, 2, 1, 1, 64);
     }
 #undef GO
 }
