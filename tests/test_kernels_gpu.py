@@ -135,7 +135,8 @@ def test_layernorm(L, C_):
     assert (outB.float().cpu() - exp).abs().max() < 8e-3 * exp.abs().max()
 
 
-@pytest.mark.parametrize("shape", [(96, 20, 24), (192, 13, 10), (256, 25, 40), (384, 9, 16), (768, 10, 10), (1536, 5, 8)])
+@pytest.mark.parametrize("shape", [(96, 20, 24), (192, 13, 10), (256, 25, 40), (384, 9, 16), (768, 10, 10), (1536, 5, 8),
+                                   (192, 101, 163), (192, 151, 163), (768, 49, 83)])   # last three: 8-px and 2-row variants
 def test_dwconv7_ln(L, shape):
     C_, H, W = shape
     g = torch.Generator().manual_seed(C_ + H)

@@ -13,8 +13,9 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
+SC = int(os.environ.get("NORM_SCALE", "1"))
 print("dwconv7_ln  (H, W, C): us, GB/s (algorithmic 6 B/elem)")
-for H, W, C in [(200, 320, 192), (100, 160, 384), (50, 80, 768), (25, 40, 1536), (100, 160, 256), (50, 80, 256), (25, 40, 256), (200, 320, 96)]:
+for H, W, C in [(h * SC, w, c) for (h, w, c) in [(200, 320, 192), (100, 160, 384), (50, 80, 768), (25, 40, 1536), (100, 160, 256), (50, 80, 256), (25, 40, 256), (200, 320, 96)]]:
     x = torch.randn(H * W, C, device="cuda"); w = torch.randn(49, C, device="cuda"); b = torch.randn(C, device="cuda")
     g = torch.randn(C, device="cuda"); be = torch.randn(C, device="cuda"); out = torch.empty(H * W, C, device="cuda", dtype=torch.bfloat16)
     us = timeit(lambda: L.check(lib.uni_dwconv7_ln(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(g), L.ptr(be), 1e-6, H, W, C, L.ptr(out), L.stream_ptr()), "dw"))

@@ -9,6 +9,7 @@
 // The reference axis is additionally split across blocks (flash-decoding style) to fill 256 CUs; a tiny
 // second kernel merges the (max, sum, acc) partials.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 constexpr int CD = 128;      // embedding dim (unicorn.py:41-44)
@@ -178,7 +179,8 @@ __global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restric
 
 int pick_nsplit(int R, int Q) {
     int nqb = cdiv(Q, QB);
-    int ns = cdiv(512, nqb);          // aim for >= 512 blocks (2048 waves over 1024 SIMDs)
+    static const char* env = getenv("UNI_CORR_BLOCKS");
+    int ns = cdiv(env ? atoi(env) : 512, nqb);          // aim for >= 512 blocks (2048 waves over 1024 SIMDs)
     int maxs = R / 256;               // keep >= 8 tiles per split
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;

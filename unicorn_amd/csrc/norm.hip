@@ -156,29 +156,26 @@ int launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
 template <int NV>
 __device__ __forceinline__ void strip_reduce(const float (&vals)[NV], float (&tot)[NV], float* lds, int S, int CG,
                                              int sl, int cg, bool active) {
+    // level 1: every thread parks its NV partials in LDS; level 2: each (strip, pixel) pair is summed by a 16-lane
+    // group (strided loads + 4 xor-shuffles) -- deterministic order, ~CG/16 dependent LDS reads instead of CG/8 + CG/8.
     const int T = blockDim.x, tid = threadIdx.x;
     const int NP = S * NV;                 // (strip, pixel) pairs
-    const int R = (CG + 7) >> 3;           // slices of 8 channel groups
     float* l1 = lds;                       // [NP][CG]
-    float* l2 = l1 + NP * CG;              // [NP][R]
-    float* l3 = l2 + NP * R;               // [NP]
+    float* l3 = l1 + NP * CG;              // [NP]
     if (active) {
 #pragma unroll
         for (int o = 0; o < NV; ++o) l1[(sl * NV + o) * CG + cg] = vals[o];
     }
     __syncthreads();
-    for (int u = tid; u < NP * R; u += T) {
-        int pr = u / R, sc = u - pr * R;
-        int e = min(CG, sc * 8 + 8);
+    const int g = tid & 15;
+    for (int u = tid >> 4; u < NP; u += T >> 4) {
         float s = 0.f;
-        for (int c = sc * 8; c < e; ++c) s += l1[pr * CG + c];
-        l2[u] = s;
-    }
-    __syncthreads();
-    for (int u = tid; u < NP; u += T) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s += l2[u * R + r];
-        l3[u] = s;
+        for (int c = g; c < CG; c += 16) s += l1[u * CG + c];
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (g == 0) l3[u] = s;
     }
     __syncthreads();
     if (active) {
@@ -188,8 +185,8 @@ __device__ __forceinline__ void strip_reduce(const float (&vals)[NV], float (&to
     __syncthreads();
 }
 static size_t strip_reduce_lds(int S, int CG, int NV) {
-    int NP = S * NV, R = (CG + 7) / 8;
-    return (size_t)(NP * CG + NP * R + NP) * sizeof(float);
+    int NP = S * NV;
+    return (size_t)(NP * CG + NP) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,6 +206,12 @@ __device__ __forceinline__ void dw_load_row(f32x4 (&dst)[IN], const DwLnArgs& p,
         if (rok && ix >= 0 && ix < p.W) v = *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * p.C);
         dst[j] = v;
     }
+}
+
+template <int IN>
+__device__ __forceinline__ void dw_load_row_interior(f32x4 (&dst)[IN], const float* rowp, int C) {
+#pragma unroll
+    for (int j = 0; j < IN; ++j) dst[j] = *reinterpret_cast<const f32x4*>(rowp + (size_t)j * C);
 }
 
 template <int PX>
@@ -239,22 +242,47 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
     }
     if (active) {
         f32x4 cur[IN], nxt[IN];
-        dw_load_row<IN>(cur, p, img0, y - 3, x0, cg);
+        // interior strips (all 7 rows and the 6-pixel halo inside the image: > 90 % of a 200x320 map) take a
+        // branch-free path; border strips use the predicated loader
+        const bool interior = y >= 3 && y + 3 < p.H && x0 >= 3 && x0 + PX + 3 <= p.W;
+        if (interior) {
+            const float* base = p.x + (img0 + (size_t)(y - 3) * p.W + (x0 - 3)) * C + cg * 4;
+            const size_t rstride = (size_t)p.W * C;
+            dw_load_row_interior<IN>(cur, base, C);
 #pragma unroll 1
-        for (int ky = 0; ky < 7; ++ky) {
-            if (ky < 6) dw_load_row<IN>(nxt, p, img0, y + ky - 2, x0, cg);      // prefetch the next input row
-            const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
+            for (int ky = 0; ky < 7; ++ky) {
+                if (ky < 6) dw_load_row_interior<IN>(nxt, base + (size_t)(ky + 1) * rstride, C);
+                const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+                for (int kx = 0; kx < 7; ++kx) {
+                    f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
 #pragma unroll
-                for (int o = 0; o < PX; ++o) {
+                    for (int o = 0; o < PX; ++o) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[e], cur[o + kx][e], acc[o][e]);
+                        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[e], cur[o + kx][e], acc[o][e]);
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < IN; ++j) cur[j] = nxt[j];
+                for (int j = 0; j < IN; ++j) cur[j] = nxt[j];
+            }
+        } else {
+            dw_load_row<IN>(cur, p, img0, y - 3, x0, cg);
+#pragma unroll 1
+            for (int ky = 0; ky < 7; ++ky) {
+                if (ky < 6) dw_load_row<IN>(nxt, p, img0, y + ky - 2, x0, cg);      // prefetch the next input row
+                const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+#pragma unroll
+                    for (int o = 0; o < PX; ++o) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[e], cur[o + kx][e], acc[o][e]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < IN; ++j) cur[j] = nxt[j];
+            }
         }
     }
     float part[PX], tot[PX];
@@ -262,9 +290,10 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
     for (int o = 0; o < PX; ++o) part[o] = acc[o][0] + acc[o][1] + acc[o][2] + acc[o][3];
     strip_reduce<PX>(part, tot, lds, S, CG, sl, cg, active);
     float mean[PX];
+    const float invC = 1.f / (float)C;
 #pragma unroll
     for (int o = 0; o < PX; ++o) {
-        mean[o] = tot[o] / C;
+        mean[o] = tot[o] * invC;
         float a = acc[o][0] - mean[o], b = acc[o][1] - mean[o], c = acc[o][2] - mean[o], d = acc[o][3] - mean[o];
         part[o] = a * a + b * b + c * c + d * d;
     }
@@ -275,10 +304,104 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
 #pragma unroll
     for (int o = 0; o < PX; ++o) {
         if (x0 + o < p.W) {
-            float rstd = 1.f / sqrtf(tot[o] / C + p.eps);
+            float rstd = rsqrtf(tot[o] * invC + p.eps);
             act_store4(p.out, (img0 + (size_t)y * p.W + x0 + o) * C + cg * 4, (acc[o][0] - mean[o]) * rstd * g[0] + be[0],
                        (acc[o][1] - mean[o]) * rstd * g[1] + be[1], (acc[o][2] - mean[o]) * rstd * g[2] + be[2],
                        (acc[o][3] - mean[o]) * rstd * g[3] + be[3], p.b32);
+        }
+    }
+}
+
+// Two output rows per thread (8 px x 2 rows x 4 ch): the 8 input rows of the window are each loaded once and feed
+// both output rows, cutting the L1/TA traffic per output by 1.8x (the single-row kernel is L1-bandwidth bound on
+// large maps: ~4.6 16-byte loads per output float4, ~15 TB/s of L1 traffic at 1.3 TB/s algorithmic).
+__global__ __launch_bounds__(384) void dwconv7_ln2_kernel(DwLnArgs p, int S, int CG, int spr, int nstrips) {
+    constexpr int PX = 8, IN = PX + 6;
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, sl = tid / CG;
+    int blk;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int strip = blk * S + sl;
+    const bool active = sl < S && strip < nstrips;
+    const int HP = (p.H + 1) >> 1;                               // row pairs per image
+    const int yg = active ? strip / spr : 0;
+    const int x0 = active ? (strip - yg * spr) * PX : 0;
+    const int sb = yg / HP, y = (yg - sb * HP) * 2;              // sample, first of the two output rows
+    const size_t img0 = (size_t)sb * p.H * p.W;
+    const int C = p.C;
+    f32x4 acc0[PX], acc1[PX];
+    {
+        f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
+#pragma unroll
+        for (int o = 0; o < PX; ++o) { acc0[o] = b; acc1[o] = b; }
+    }
+    if (active) {
+        f32x4 cur[IN];
+#pragma unroll 1
+        for (int r = 0; r < 8; ++r) {                            // input row y-3+r: ky = r for row y, ky = r-1 for row y+1
+            dw_load_row<IN>(cur, p, img0, y - 3 + r, x0, cg);
+            if (r < 7) {
+                const float* wrow = p.w + (size_t)(r * 7) * C + cg * 4;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+#pragma unroll
+                    for (int o = 0; o < PX; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc0[o][e] = fmaf(w[e], cur[o + kx][e], acc0[o][e]);
+                }
+            }
+            if (r > 0) {
+                const float* wrow = p.w + (size_t)((r - 1) * 7) * C + cg * 4;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+#pragma unroll
+                    for (int o = 0; o < PX; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc1[o][e] = fmaf(w[e], cur[o + kx][e], acc1[o][e]);
+                }
+            }
+        }
+    }
+    float part[2 * PX], tot[2 * PX], mean[2 * PX];
+#pragma unroll
+    for (int o = 0; o < PX; ++o) {
+        part[o] = acc0[o][0] + acc0[o][1] + acc0[o][2] + acc0[o][3];
+        part[PX + o] = acc1[o][0] + acc1[o][1] + acc1[o][2] + acc1[o][3];
+    }
+    strip_reduce<2 * PX>(part, tot, lds, S, CG, sl, cg, active);
+    const float invC = 1.f / (float)C;
+#pragma unroll
+    for (int o = 0; o < PX; ++o) {
+        mean[o] = tot[o] * invC;
+        mean[PX + o] = tot[PX + o] * invC;
+        float a = acc0[o][0] - mean[o], b = acc0[o][1] - mean[o], c = acc0[o][2] - mean[o], d = acc0[o][3] - mean[o];
+        part[o] = a * a + b * b + c * c + d * d;
+        a = acc1[o][0] - mean[PX + o]; b = acc1[o][1] - mean[PX + o]; c = acc1[o][2] - mean[PX + o]; d = acc1[o][3] - mean[PX + o];
+        part[PX + o] = a * a + b * b + c * c + d * d;
+    }
+    strip_reduce<2 * PX>(part, tot, lds, S, CG, sl, cg, active);
+    if (!active) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + cg * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cg * 4);
+#pragma unroll
+    for (int o = 0; o < PX; ++o) {
+        if (x0 + o < p.W) {
+            float rstd = rsqrtf(tot[o] * invC + p.eps);
+            act_store4(p.out, (img0 + (size_t)y * p.W + x0 + o) * C + cg * 4, (acc0[o][0] - mean[o]) * rstd * g[0] + be[0],
+                       (acc0[o][1] - mean[o]) * rstd * g[1] + be[1], (acc0[o][2] - mean[o]) * rstd * g[2] + be[2],
+                       (acc0[o][3] - mean[o]) * rstd * g[3] + be[3], p.b32);
+            if (y + 1 < p.H) {
+                rstd = rsqrtf(tot[PX + o] * invC + p.eps);
+                act_store4(p.out, (img0 + (size_t)(y + 1) * p.W + x0 + o) * C + cg * 4,
+                           (acc1[o][0] - mean[PX + o]) * rstd * g[0] + be[0], (acc1[o][1] - mean[PX + o]) * rstd * g[1] + be[1],
+                           (acc1[o][2] - mean[PX + o]) * rstd * g[2] + be[2], (acc1[o][3] - mean[PX + o]) * rstd * g[3] + be[3], p.b32);
+            }
         }
     }
 }
@@ -289,11 +412,18 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     int S = 256 / CG;
     if (S < 1) S = 1;
     const int T = cdiv(S * CG, 64) * 64;
-    // PX = 8 only when the 8-pixel strips alone already give >= 8 waves per SIMD
+    // variant by the thread count n8 of the 8-px single-row tiling (measured crossovers, tools/norm_bench.py):
+    // n8 >= 150k -> 2 rows x 8 px, >= 70k -> 8 px, else 4 px (more, smaller threads to fill the 256 CUs)
     static const char* env = getenv("UNI_DW_PX");
     const int nb = a.B > 0 ? a.B : 1;
-    int px = ((long)cdiv(a.W, 8) * a.H * nb * CG >= 300000L) ? 8 : 4;   // measured crossover (tools/norm_bench.py)
+    const long n8 = (long)cdiv(a.W, 8) * a.H * nb * CG;
+    int px = n8 >= 150000L ? 16 : n8 >= 70000L ? 8 : 4;
     if (env) px = atoi(env);
+    if (px == 16) {
+        const int spr = cdiv(a.W, 8), nstrips = spr * ((a.H + 1) / 2) * nb;
+        hipLaunchKernelGGL(dwconv7_ln2_kernel, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 16), s, a, S, CG, spr, nstrips);
+        return 0;
+    }
     if (px == 8) {
         const int spr = cdiv(a.W, 8), nstrips = spr * a.H * nb;
         hipLaunchKernelGGL(dwconv7_ln_kernel<8>, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 8), s, a, S, CG, spr, nstrips);
