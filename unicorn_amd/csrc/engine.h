@@ -16,7 +16,7 @@ struct PBlock { float* dw_w = nullptr; float* dw_b = nullptr; PAffine ln; PConv 
 struct PBaseConv { PConv conv; PAffine gn; int k = 1, stride = 1; };
 struct PCsp { PConv c12; PAffine gn12; PBaseConv m1[3], m2[3], c3; int cin = 0, cout = 0, h = 0; };
 
-struct ProfRec { hipEvent_t a, b; double work; int cls; };
+struct ProfRec { hipEvent_t a, b; double work; int cls; int M = 0, N = 0, K = 0, conv = 0; };
 
 struct uni_ctx {
     int device = 0;

@@ -364,15 +364,18 @@ static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
         c->prof_bytes += (double)g.Hin * g.Win * g.Cin * es + (double)g.N * g.K * es +
                          (double)g.M * g.N * ((g.outF ? 4.0 : 0.0) + (g.outB ? es : 0.0) + (g.res ? 4.0 : 0.0));
     }
-    return prof_run(c, PC_GEMM, 2.0 * g.M * g.N * g.K, s, [&] { return launch_gemm(g, s); });
+    const size_t before = c->recs.size();
+    int rc = prof_run(c, PC_GEMM, 2.0 * g.M * g.N * g.K, s, [&] { return launch_gemm(g, s); });
+    if (c->recs.size() > before) { ProfRec& r = c->recs.back(); r.M = g.M; r.N = g.N; r.K = g.K; r.conv = g.KH * 10 + g.stride; }
+    return rc;
 }
 static int p_dwln(uni_ctx* c, DwLnArgs d, hipStream_t s) {
     d.b32 = c->b32;
-    return prof_run(c, PC_DWLN, (double)d.H * d.W * d.C * 6.0 + 49.0 * d.C * 4, s, [&] { return launch_dwconv7_ln(d, s); });
+    return prof_run(c, PC_DWLN, (double)(d.B > 0 ? d.B : 1) * d.H * d.W * d.C * 6.0 + 49.0 * d.C * 4, s, [&] { return launch_dwconv7_ln(d, s); });
 }
 static int p_gn(uni_ctx* c, GnApplyArgs a, hipStream_t s) {
     a.b32 = c->b32;
-    double b = (double)a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0) + (a.outUp ? 8 : 0));
+    double b = (double)(a.B > 0 ? a.B : 1) * a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0) + (a.outUp ? 8 : 0));
     return prof_run(c, PC_GN, b, s, [&] { return launch_gn_apply(a, s); });
 }
 static int p_ln(uni_ctx* c, LnArgs a, hipStream_t s) {
@@ -392,12 +395,16 @@ int engine_prof_end(uni_ctx* c, double* out) {   // out[PC_NCLS][3] = {ms, work,
     UNI_CHECK_HIP(hipDeviceSynchronize());
     for (int i = 0; i < PC_NCLS * 3; ++i) out[i] = 0.0;
     out[PC_NCLS * 3] = c->prof_bytes;
+    // UNI_PROF_DUMP=<path>: one line per profiled launch (class, M, N, K, conv code KH*10+stride, us, work)
+    FILE* dump = getenv("UNI_PROF_DUMP") ? fopen(getenv("UNI_PROF_DUMP"), "a") : nullptr;
     for (auto& r : c->recs) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
+        if (dump) fprintf(dump, "%d %d %d %d %d %.2f %.6g\n", r.cls, r.M, r.N, r.K, r.conv, ms * 1e3, r.work);
         out[r.cls * 3 + 0] += ms; out[r.cls * 3 + 1] += r.work; out[r.cls * 3 + 2] += 1;
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
+    if (dump) fclose(dump);
     c->recs.clear();
     return 0;
 }

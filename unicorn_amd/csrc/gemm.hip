@@ -38,6 +38,95 @@ __device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
         (x) = ((long)_hi << 32) | (unsigned)_lo;         \
     } while (0)
 
+// ---- LDS-staged stores.  The MFMA leaves each lane with 4-channel quads of ONE pixel row, so direct stores touch
+// 64 different cache lines per wave instruction (16 B each) and the store phase runs at ~2-3 TB/s with the MFMA pipe
+// idle (measured: 40-80 % on top of the K loop for the ConvNeXt MLP shapes).  Instead every wave transposes its
+// 32 x (32 TN) accumulator slab through a private fp32 LDS tile (XOR-swizzled float4 chunks, conflict-free both ways;
+// the operand buffers are dead by now) and writes whole rows: a wave instruction covers 8 full 128-B lines (bf16) or
+// 4 x 256 B (fp32); residual reads are coalesced the same way.  Only wave-local ordering is needed (in-order LDS).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                  int lane, char* smem) {
+    constexpr int CW = 32 * TN;            // wave tile width in channels
+    constexpr int CPRo = CW / 4;           // float4 chunks per staged row (8 or 16)
+    float* st = reinterpret_cast<float*>(smem) + (wm * WN + wn) * (32 * CW);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nw0 = n0 + wn * CW;
+    __syncthreads();                       // all waves are done with the last operand tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // phase A: bias + activation in the MFMA layout, float4 chunks to LDS [row fr][chunk ^ (fr & 7)]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = nw0 + j * 32 + 8 * g + 4 * fh;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (col < p.N) {
+                    if (p.bias) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+                        v += b4;
+                    }
+                    if (p.act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (col + e >= p.act_col0) ? act_apply_fast(v[e], p.act) : v[e];
+                    }
+                }
+                const int c = j * 8 + 2 * g + fh;
+                *reinterpret_cast<f32x4*>(st + fr * CW + ((c ^ (fr & 7)) << 2)) = v;
+            }
+        }
+        wave_lds_fence();
+        // phase B: whole rows out
+        const int rbase = m0 + wm * 32 * TM + i * 32;
+        if (!p.outF && !p.res) {
+            constexpr int Q = CW / 8, RPI = 64 / Q;        // 8-channel (16-B bf16) pieces per row, rows per instruction
+            const int q = lane % Q, rr = lane / Q;
+            const int col = nw0 + 8 * q;
+#pragma unroll
+            for (int t = 0; t < 32 / RPI; ++t) {
+                const int r = t * RPI + rr, row = rbase + r;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * CW + (((2 * q) ^ (r & 7)) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * CW + (((2 * q + 1) ^ (r & 7)) << 2));
+                if (row < p.M && col < p.N && !(p.dbg & 128)) {
+                    bf16x2 w0 = {(bf16)lo[0], (bf16)lo[1]}, w1 = {(bf16)lo[2], (bf16)lo[3]};
+                    bf16x2 w2 = {(bf16)hi[0], (bf16)hi[1]}, w3 = {(bf16)hi[2], (bf16)hi[3]};
+                    u32x4 o4 = {__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w1),
+                                __builtin_bit_cast(unsigned, w2), __builtin_bit_cast(unsigned, w3)};
+                    *reinterpret_cast<u32x4*>(p.outB + (size_t)row * p.ldb + col) = o4;
+                }
+            }
+        } else {
+            constexpr int RPI = 64 / CPRo;
+            const int c = lane % CPRo, rr = lane / CPRo;
+            const int col = nw0 + 4 * c;
+#pragma unroll
+            for (int t = 0; t < 32 / RPI; ++t) {
+                const int r = t * RPI + rr, row = rbase + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + r * CW + ((c ^ (r & 7)) << 2));
+                if (row < p.M && col < p.N && !(p.dbg & 128)) {
+                    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+                    if (p.outF) {
+                        const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
+                        *reinterpret_cast<f32x4*>(p.outF + (size_t)orow * p.ldf + col) = v;
+                    }
+                    if (p.outB) {
+                        bf16x2 w0 = {(bf16)v[0], (bf16)v[1]}, w1 = {(bf16)v[2], (bf16)v[3]};
+                        u32x2 o2 = {__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w1)};
+                        *reinterpret_cast<u32x2*>(p.outB + (size_t)row * p.ldb + col) = o2;
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 // ---- shared epilogue: lane owns pixel row = m0 + wm*32*TM + i*32 + (lane&31) and, per accumulator quad g,
 // channels n0 + wn*32*TN + j*32 + 8g + 4*(lane>>5) + {0,1,2,3} ----
 template <int WM, int WN, int TM, int TN, bool STATS>
@@ -46,8 +135,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     constexpr int BN = 32 * TN * WN, BMt = 32 * TM * WM;
     const int fr = lane & 31, fh = lane >> 5;
     const bool vec_ok = (p.N & 3) == 0;
+    // the 8/16-wave tiles (register budget 128-256) are only launched with staged stores; the direct path is compiled out
+    constexpr bool ONLY_STAGED = WM * WN > 4;
+    if (ONLY_STAGED || p.epi) gemm_store_staged<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, smem);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < ((ONLY_STAGED || p.epi) ? 0 : TM); ++i) {
         const int row = m0 + wm * 32 * TM + i * 32 + fr;
         const bool rok = row < p.M;
 #pragma unroll
@@ -281,6 +373,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         bn = c * GN + rem - bm * wc;
     }
     const int m0 = bm * BM, n0 = bn * BN;
+    if ((p.dbg & 64) && (blockIdx.x & 8) && blockIdx.x < 256) {   // experiment: de-phase half of the first-round blocks
+        for (int z = 0; z < (p.dbg >> 8); ++z) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- per-lane DMA source descriptors ----
     // piece pc = wave + NW*i covers tile rows RPP*pc .. RPP*pc+RPP-1; lane -> row RPP*pc + lane/CPR, physical chunk
@@ -381,6 +476,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
         }
     }
 
+    if (p.dbg & 16) {   // ablation: no epilogue (accumulators kept live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 1.2345e-30f && p.outF) p.outF[0] = sacc;
+        return;
+    }
     gemm_epilogue<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
@@ -523,6 +629,12 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     // the global->LDS fill rate, so the biggest block tile that still yields >= ~1.5 blocks per CU wins (256x256,
     // 16 waves); small problems want >= ~400 blocks of a smaller tile; implicit convs amortise their gather
     // address math over wider-N tiles.
+    {   // LDS-staged row-coalesced stores need vector-aligned operands; odd widths (cls/obj/reg heads) keep the direct path
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        a.epi = (a.N % 8 == 0) && (!a.bias || al16(a.bias)) && (!a.res || (a.ldr % 4 == 0 && al16(a.res))) &&
+                (!a.outF || (a.ldf % 4 == 0 && al16(a.outF))) && (!a.outB || (a.ldb % 8 == 0 && al16(a.outB))) &&
+                !((a.force_cfg / 1000) & 32);
+    }
     const long b44 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     const long b22 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b21 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
@@ -537,6 +649,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         else cfg = b21 >= 400 ? 21 : 11;
     }
 #define GO(WM, WN, TM, TN, BK) return conv ? launch_cfg<WM, WN, TM, TN, BK, true>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false>(a, s)
+    if (!a.epi && (cfg == 44 || cfg == 42 || cfg == 24)) cfg = 22;
     switch (cfg) {   // 2-digit codes: 4 waves (2x2), wave tile 32TM x 32TN; 44 / 42 / 24: 16 / 8 / 8 waves of 64x64 wave tiles
         case 44: GO(4, 4, 2, 2, 64);     // 256 x 256 block tile, 128 KiB LDS
         case 42: GO(4, 2, 2, 2, 64);     // 256 x 128

@@ -21,6 +21,7 @@ struct GemmArgs {
     int force_cfg = 0;                        // 0 = heuristic, else 22 / 12 / 21 / 11
     int b32 = 0;                              // exact-fp32 mode: A, W and outB are fp32 (v_mfma_f32_32x32x2_f32)
     int dbg = 0;                              // ablation switches for tools/gemm_bench.py (1 = no DMA after tile 0, 2 = no MFMA)
+    int epi = 0;                              // set by launch_gemm: 1 = LDS-staged, row-coalesced epilogue stores
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
