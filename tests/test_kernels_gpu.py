@@ -97,6 +97,40 @@ def test_gemm_conv(L, cfg, case):
         assert torch.allclose(s_got, s_ref, rtol=1e-3, atol=1e-2), (s_got - s_ref).abs().max()
 
 
+@pytest.mark.parametrize("cfg", [88, 44, 0])
+@pytest.mark.parametrize("case", [
+    # (M, N, K, act, res, outF, outB): > 256 tiles of 256x128 so persistent blocks walk several tiles
+    (70001, 256, 64, 2, False, False, True),      # one K step per tile (drain slices outnumber K steps), GELU, bf16 out
+    (35003, 512, 136, 0, True, True, True),       # K tail (136 -> 3 steps), residual + fp32 + bf16 out, ragged M
+    (9001, 3072, 320, 2, False, False, True),     # pwconv1-like
+    (20000, 768, 1024, 0, True, True, False),     # pwconv2-like, fp32 out only
+    (5000, 136, 256, 3, False, True, True),       # N not a multiple of the tile (136 = 128 + 8)
+])
+def test_gemm_large(L, cfg, case):
+    M, N, K, act, use_res, use_F, use_B = case
+    g = torch.Generator().manual_seed(M + N + K)
+    x = bf16_round(torch.randn(M, K, generator=g)).cuda()
+    w = bf16_round(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    res = torch.randn(M, N, generator=g).cuda() if use_res else None
+    raw = x @ w.cuda().t() + bias                     # fp32 on the same bf16-rounded operands
+    exp = ACTS[act](raw) + (res if use_res else 0)
+    A = x.to(torch.bfloat16)
+    Wp = pack_weight(L, w.reshape(N, K, 1, 1))
+    outF = torch.full((M, N), float("nan"), device="cuda") if use_F else None
+    outB = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) if use_B else None
+    L.check(L.lib().uni_gemm_bf16(L.ptr(A), K, L.ptr(Wp), M, N, M, 1, K, 1, 1, 1, 0, L.ptr(bias), act, L.ptr(res), N,
+                                  L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg, L.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    scale = max(1.0, exp.abs().max().item())
+    if use_F:
+        assert torch.isfinite(outF).all()
+        assert (outF - exp).abs().max().item() < 2e-3 * scale
+    if use_B:
+        assert torch.isfinite(outB.float()).all()
+        assert (outB.float() - exp).abs().max().item() < 1e-2 * scale
+
+
 def test_gemm_act_col0(L):
     g = torch.Generator().manual_seed(5)
     M, K, N = 300, 256, 5

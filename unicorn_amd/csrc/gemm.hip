@@ -649,7 +649,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         else cfg = b21 >= 400 ? 21 : 11;
     }
 #define GO(WM, WN, TM, TN, BK) return conv ? launch_cfg<WM, WN, TM, TN, BK, true>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false>(a, s)
+    if (cfg == 88 && !gemm_pipe_supported(a)) cfg = 44;
     if (!a.epi && (cfg == 44 || cfg == 42 || cfg == 24)) cfg = 22;
+    if (cfg == 88) return launch_gemm_pipe(a, s);
     switch (cfg) {   // 2-digit codes: 4 waves (2x2), wave tile 32TM x 32TN; 44 / 42 / 24: 16 / 8 / 8 waves of 64x64 wave tiles
         case 44: GO(4, 4, 2, 2, 64);     // 256 x 256 block tile, 128 KiB LDS
         case 42: GO(4, 2, 2, 2, 64);     // 256 x 128

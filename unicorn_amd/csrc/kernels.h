@@ -24,6 +24,8 @@ struct GemmArgs {
     int epi = 0;                              // set by launch_gemm: 1 = LDS-staged, row-coalesced epilogue stores
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+int launch_gemm_pipe(const GemmArgs& a, hipStream_t s);
+bool gemm_pipe_supported(const GemmArgs& a);   // gemm_pipe.hip: persistent 256x128 tiles, drain overlapped with the next tile
 
 // ---------------------------------------------------------------- norm.hip
 // Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.
