@@ -48,7 +48,7 @@ def pack_weight(L, w):
 ACTS = {0: lambda x: x, 1: F.relu, 2: F.gelu, 3: F.silu, 4: torch.sigmoid}
 
 
-@pytest.mark.parametrize("cfg", [0, 22, 12, 21, 11, 122, 42, 24, 44])
+@pytest.mark.parametrize("cfg", [0, 22, 12, 21, 11, 122, 42, 24, 44, 444, 445, 224])
 @pytest.mark.parametrize("case", [
     # (Hin, Win, Cin, N, KH, stride, pad, act, bias, res, stats_G)
     (20, 24, 96, 384, 1, 1, 0, 2, True, False, 0),        # tiny pwconv1 + GELU, K=96 (padded to 128)
@@ -97,7 +97,7 @@ def test_gemm_conv(L, cfg, case):
         assert torch.allclose(s_got, s_ref, rtol=1e-3, atol=1e-2), (s_got - s_ref).abs().max()
 
 
-@pytest.mark.parametrize("cfg", [88, 44, 0])
+@pytest.mark.parametrize("cfg", [88, 44, 444, 445, 224, 0])
 @pytest.mark.parametrize("case", [
     # (M, N, K, act, res, outF, outB): > 256 tiles of 256x128 so persistent blocks walk several tiles
     (70001, 256, 64, 2, False, False, True),      # one K step per tile (drain slices outnumber K steps), GELU, bf16 out
@@ -258,17 +258,37 @@ def test_msda_random_vs_oracle(L):
     assert out0.shape == (1, 0, 256)
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("R,Q,K", [(1600, 1600, 1), (1000, 1300, 3), (4000, 2000, 5), (333, 257, 9)])
-def test_corr_softmax_pv(L, R, Q, K):
+def test_corr_softmax_pv(L, R, Q, K, prec):
     from unicorn_amd.ops import corr_softmax_pv
     g = torch.Generator().manual_seed(R + Q)
     er = torch.randn(128, R, generator=g) * 0.6
     ec = torch.randn(128, Q, generator=g) * 0.6
     v = torch.rand(K, R, generator=g)
     ref = uo.correlation_propagate(er, ec, v)
-    out = corr_softmax_pv(er.cuda(), ec.cuda(), v.cuda())
+    out = corr_softmax_pv(er.cuda(), ec.cuda(), v.cuda(), precision=prec)
     err = (out.cpu() - ref).abs().max().item()
     assert err < 2e-5, err
+
+
+def test_corr_split_matches_fp32_mfma(L):
+    """bf16x3 split (precision 1) against the exact fp32 MFMA kernel (precision 0) at 800x1280 scale with large logits
+    (|logit| up to ~60, where softmax amplifies any contraction error), and against an fp64 evaluation"""
+    from unicorn_amd.ops import corr_softmax_pv
+    g = torch.Generator().manual_seed(11)
+    R = Q = 16000
+    er = (torch.randn(128, R, generator=g) * 1.3).cuda()
+    ec = (torch.randn(128, Q, generator=g) * 1.3).cuda()
+    v = torch.rand(3, R, generator=g).cuda()
+    o0 = corr_softmax_pv(er, ec, v, precision=0)
+    o1 = corr_softmax_pv(er, ec, v, precision=1)
+    qs = torch.arange(0, Q, 97, device="cuda")
+    ref = (v.double() @ torch.softmax(er.double().t() @ ec[:, qs].double(), 0)).float()
+    e0 = (o0[:, qs] - ref).abs().max().item()
+    e1 = (o1[:, qs] - ref).abs().max().item()
+    assert (o0 - o1).abs().max().item() < 2e-5
+    assert e1 < max(3 * e0, 2e-6), (e0, e1)     # same error class as the fp32 MFMA path
 
 
 def test_corr_spiked_rescale(L):
@@ -282,9 +302,10 @@ def test_corr_spiked_rescale(L):
     er[:, 5] = ec[:, 100] * 40           # and at the first tile for query 100
     v = torch.rand(2, R, generator=g)
     ref = uo.correlation_propagate(er, ec, v)
-    out = corr_softmax_pv(er.cuda(), ec.cuda(), v.cuda()).cpu()
-    assert (out - ref).abs().max() < 2e-5
-    assert abs(out[0, 7] - v[0, 1900]) < 1e-4 and abs(out[1, 100] - v[1, 5]) < 1e-4
+    for prec in (0, 1):
+        out = corr_softmax_pv(er.cuda(), ec.cuda(), v.cuda(), precision=prec).cpu()
+        assert (out - ref).abs().max() < 2e-5
+        assert abs(out[0, 7] - v[0, 1900]) < 1e-4 and abs(out[1, 100] - v[1, 5]) < 1e-4
 
 
 def test_prior_pyramid_label_map(L):

@@ -156,6 +156,176 @@ __global__ __launch_bounds__(256, 2) void corr_f32_kernel(const float* __restric
     }
 }
 
+// ---- precision 1: fp32-equivalent contraction on the bf16 MFMA pipe ("bf16x3"): every fp32 operand is split exactly into
+// three bf16 pieces x = h + m + l (8+8+8 significand bits); the six products h.h, h.m, m.h, h.l, m.m, l.h are each exact in
+// fp32 and are accumulated in the fp32 MFMA accumulator; the dropped terms (m.l, l.m, l.l) are <= 2^-24 relative, i.e. at
+// the level of fp32 rounding itself.  6 x v_mfma_f32_32x32x16_bf16 (32 cyc each) per 16-deep slice instead of
+// 8 x v_mfma_f32_32x32x2_f32 (64 cyc each): 2.67x less MFMA time at fp32-class accuracy (the reference itself runs this
+// product in fp16).  8 waves x 32 queries share one 32-row reference tile; the tile is split while it is staged:
+// LDS = 3 planes [32 rows][128 dims] bf16, 16-B chunks XOR-swizzled with (row & 15) (conflict-free ds_read_b128).
+constexpr int QB2 = 256;     // query columns per block in the 8-wave variant (NWV x 32)
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16 hh = (bf16)x[e];
+        const float r1 = x[e] - (float)hh;
+        const bf16 mm = (bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (bf16)r2;
+    }
+}
+
+template <int KV, int NWV>
+__global__ __launch_bounds__(64 * NWV) void corr_split_kernel(const float* __restrict__ eref, const float* __restrict__ ecur,
+                                                         const float* __restrict__ v, float* __restrict__ out,
+                                                         float* __restrict__ ws, int R, int Q, int K, int nsplit,
+                                                         int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PLANE = TR * CD;                       // bf16 elements per piece plane (32 x 128)
+    bf16* As = reinterpret_cast<bf16*>(smem);            // [2 buffers][3 planes][TR][CD]
+    float* Vs = smem + (2 * 3 * PLANE) / 2;              // [2][KV*TR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int split = blockIdx.y;
+    const int q = blockIdx.x * (32 * NWV) + wave * 32 + fr;
+    const int qc = q < Q ? q : Q - 1;
+
+    // stationary operand: MFMA slice c contracts dims 16c .. 16c+15, this lane carries dims 16c + 8 fh + (0..7)
+    bf16x8 qh[8], qm[8], ql[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(ecur + (size_t)qc * CD + 16 * c + 8 * fh);
+        const f32x4 t0 = src[0], t1 = src[1];
+        const float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        split3(x, qh[c], qm[c], ql[c]);
+    }
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+    const int ntiles = (r_end - r_begin + TR - 1) / TR;
+
+    // staging: the 32 x 128 tile is 512 chunks of 8 dims; thread -> chunks tid + 64*NWV*j (row = chunk/16, slot = chunk%16)
+    constexpr int SPT = 512 / (64 * NWV);            // chunks per thread (1 or 2)
+    f32x4 g0[SPT], g1[SPT];
+    float gv;
+    auto gload = [&](int t) __attribute__((always_inline)) {
+        const int r0 = r_begin + t * TR;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int ch = tid + 64 * NWV * j;
+            const int row = min(r0 + (ch >> 4), R - 1);
+            const f32x4* src = reinterpret_cast<const f32x4*>(eref + (size_t)row * CD + (ch & 15) * 8);
+            g0[j] = src[0]; g1[j] = src[1];
+        }
+        const int k = tid >> 5, r = r0 + (tid & 31);
+        gv = (k < K && k < KV && r < R) ? v[(size_t)k * R + r] : 0.f;
+    };
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int ch = tid + 64 * NWV * j, srow = ch >> 4, sch = ch & 15;
+            const float x[8] = {g0[j][0], g0[j][1], g0[j][2], g0[j][3], g1[j][0], g1[j][1], g1[j][2], g1[j][3]};
+            bf16x8 h, m, l;
+            split3(x, h, m, l);
+            bf16* dst = As + buf * 3 * PLANE + srow * CD + ((sch ^ (srow & 15)) << 3);
+            *reinterpret_cast<bf16x8*>(dst) = h;
+            *reinterpret_cast<bf16x8*>(dst + PLANE) = m;
+            *reinterpret_cast<bf16x8*>(dst + 2 * PLANE) = l;
+        }
+        if (tid < KV * TR) Vs[buf * KV * TR + tid] = gv;
+    };
+
+    float m = -INFINITY, l = 0.f, o[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) o[k] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        const bf16* arow = As + buf * 3 * PLANE + fr * CD;
+        // two independent accumulator chains (small cross terms / leading terms) keep the MFMA pipe back-to-back
+        f32x16 acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int off = ((2 * c + fh) ^ (fr & 15)) << 3;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + off);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(arow + PLANE + off);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(arow + 2 * PLANE + off);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qm[c], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qm[c], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qh[c], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+        // online softmax over this tile's 16 rows owned by the lane (same as corr_f32_kernel)
+        const int r0 = r_begin + t * TR;
+        float sc[16], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = (r0 + rowof(r, fh) < r_end) ? acc[r] : -INFINITY;
+            tmax = fmaxf(tmax, sc[r]);
+        }
+        const float mn = fmaxf(m, tmax);
+        if (mn > -INFINITY) {
+            const float f = (m > -INFINITY) ? __expf(m - mn) : 0.f;
+            l *= f;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) o[k] *= f;
+            const float* vt = Vs + buf * KV * TR;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float pr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pr[j] = __expf(sc[4 * g + j] - mn);
+                    l += pr[j];
+                }
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(vt + k * TR + 8 * g + 4 * fh);
+                    o[k] += pr[0] * v4[0] + pr[1] * v4[1] + pr[2] * v4[2] + pr[3] * v4[3];
+                }
+            }
+            m = mn;
+        }
+        if (t + 1 < ntiles) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    {
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        const float M = fmaxf(m, m2);
+        const float f1 = (m > -INFINITY) ? __expf(m - M) : 0.f;
+        const float f2 = (m2 > -INFINITY) ? __expf(m2 - M) : 0.f;
+        l = l * f1 + l2 * f2;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const float o2 = __shfl_xor(o[k], 32, 64);
+            o[k] = o[k] * f1 + o2 * f2;
+        }
+        m = M;
+    }
+    if (fh == 0 && q < Q) {
+        if (nsplit == 1) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k)
+                if (k < K) out[(size_t)k * Q + q] = o[k] / l;
+        } else {
+            float* w = ws + ((size_t)split * Q + q) * (2 + KV);
+            w[0] = m;
+            w[1] = l;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) w[2 + k] = o[k];
+        }
+    }
+}
+
 template <int KV>
 __global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int Q, int K, int nsplit) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,10 +347,14 @@ __global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restric
         if (k < K) out[(size_t)k * Q + q] = O[k] / L;
 }
 
-int pick_nsplit(int R, int Q) {
-    int nqb = cdiv(Q, QB);
+int corr_waves() {   // waves per block of the split kernel (env UNI_CORR_WAVES = 4 | 8 for experiments)
+    static const char* env = getenv("UNI_CORR_WAVES");
+    return env && atoi(env) == 8 ? 8 : 4;
+}
+int pick_nsplit(int R, int Q, int precision = 0) {
+    int nqb = cdiv(Q, precision && corr_waves() == 8 ? QB2 : QB);
     static const char* env = getenv("UNI_CORR_BLOCKS");
-    int ns = cdiv(env ? atoi(env) : 512, nqb);          // aim for >= 512 blocks (2048 waves over 1024 SIMDs)
+    int ns = cdiv(env ? atoi(env) : 1024, nqb);          // aim for >= 1024 blocks (measured, tools/corr_bench.py)
     int maxs = R / 256;               // keep >= 8 tiles per split
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
@@ -188,14 +362,24 @@ int pick_nsplit(int R, int Q) {
 }
 
 template <int KV>
-int run(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int K, float* ws,
+int run(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int K, float* ws, int precision,
         hipStream_t s) {
-    const int ns = pick_nsplit(R, Q);
+    const int ns = pick_nsplit(R, Q, precision);
     int rps = cdiv(cdiv(R, ns), TR) * TR;
     const int ns_eff = cdiv(R, rps);   // every split non-empty
-    size_t lds = (size_t)(2 * TR * LDA + 2 * KV * TR) * sizeof(float);
-    hipLaunchKernelGGL((corr_f32_kernel<KV>), dim3(cdiv(Q, QB), ns_eff), dim3(256), lds, s, eref, ecur, v, out, ws, R,
-                       Q, K, ns_eff, rps);
+    if (precision) {
+        size_t lds = (size_t)2 * 3 * TR * CD * sizeof(bf16) + (size_t)2 * KV * TR * sizeof(float);
+        if (corr_waves() == 8)
+            hipLaunchKernelGGL((corr_split_kernel<KV, 8>), dim3(cdiv(Q, 256), ns_eff), dim3(512), lds, s, eref, ecur, v, out,
+                               ws, R, Q, K, ns_eff, rps);
+        else
+            hipLaunchKernelGGL((corr_split_kernel<KV, 4>), dim3(cdiv(Q, 128), ns_eff), dim3(256), lds, s, eref, ecur, v, out,
+                               ws, R, Q, K, ns_eff, rps);
+    } else {
+        size_t lds = (size_t)(2 * TR * LDA + 2 * KV * TR) * sizeof(float);
+        hipLaunchKernelGGL((corr_f32_kernel<KV>), dim3(cdiv(Q, QB), ns_eff), dim3(256), lds, s, eref, ecur, v, out, ws, R,
+                           Q, K, ns_eff, rps);
+    }
     if (ns_eff > 1)
         hipLaunchKernelGGL((corr_merge_kernel<KV>), dim3(cdiv(Q, 256)), dim3(256), 0, s, ws, out, Q, K, ns_eff);
     return 0;
@@ -204,23 +388,24 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
 
 size_t corr_workspace_bytes(int R, int Q, int K) {
     (void)K;
-    return (size_t)pick_nsplit(R, Q) * Q * (2 + 8) * sizeof(float);
+    const int a = pick_nsplit(R, Q, 0), b = pick_nsplit(R, Q, 1);
+    return (size_t)(a > b ? a : b) * Q * (2 + 8) * sizeof(float);
 }
 
 int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,
                 int precision, void* workspace, size_t ws_bytes, hipStream_t s) {
     UNI_REQUIRE(D == CD, "corr: embedding dim %d unsupported (128)", D);
     UNI_REQUIRE(R > 0 && Q > 0 && K > 0, "corr: empty problem R=%d Q=%d K=%d", R, Q, K);
-    UNI_REQUIRE(precision == 0, "corr: precision %d not implemented", precision);
+    UNI_REQUIRE(precision == 0 || precision == 1, "corr: precision %d not implemented (0 = fp32 MFMA, 1 = bf16x3 split)", precision);
     UNI_REQUIRE(ws_bytes >= corr_workspace_bytes(R, Q, K), "corr: workspace too small");
     UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
     float* ws = reinterpret_cast<float*>(workspace);
     for (int k0 = 0; k0 < K; k0 += 8) {
         const int kc = K - k0 < 8 ? K - k0 : 8;
         int rc;
-        if (kc == 1) rc = run<1>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, s);
-        else if (kc <= 4) rc = run<4>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, s);
-        else rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, s);
+        if (kc == 1) rc = run<1>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
+        else if (kc <= 4) rc = run<4>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
+        else rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
         if (rc) return rc;
     }
     return 0;

@@ -332,7 +332,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, bool CONV, bool STATS>
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, bool STATS, int NSTG = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;                                  // waves per block, arranged WM (pixels) x WN (channels)
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int B_PC = BN / RPP / NW;
     static_assert(A_PC >= 1 && B_PC >= 1 && NW % 2 == 0, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*BK]
-    bf16* Bs = As + 2 * BM * BK;                              // [2][BN*BK]
+    bf16* As = reinterpret_cast<bf16*>(smem);                 // [NSTG][BM*BK]
+    bf16* Bs = As + NSTG * BM * BK;                           // [NSTG][BN*BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -440,11 +440,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs p) {
     const int nk = p.Kpad / BK;
     const int fr = lane & 31;          // fragment row within a 32-row sub-tile
     const int fh = lane >> 5;          // which 8-wide half of the 16-deep MFMA K step
-    issue(0, 0);
+    // NSTG == 2: one tile in flight, __syncthreads (vmcnt(0) + barrier) per K step.
+    // NSTG  > 2: NSTG-1 tiles in flight, COUNTED vmcnt (never 0 in steady state) + raw s_barrier: the K loop is bound by the
+    // global->LDS round trip (~3k cycles under load), so bandwidth scales with the bytes in flight.
+    constexpr int DEPTH = NSTG - 1, PCW = A_PC + B_PC;
+    if (NSTG > 2) {
+        for (int s_ = 0; s_ < DEPTH && s_ < nk; ++s_) issue(s_, s_);
+    } else {
+        issue(0, 0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (!(p.dbg & 8)) __syncthreads();               // tile kt landed (vmcnt(0) + barrier); everyone is done with buf^1
-        if (kt + 1 < nk && !(p.dbg & 1)) issue(kt + 1, buf ^ 1);
+        int buf;
+        if (NSTG > 2) {
+            buf = kt % NSTG;
+            const int rem = nk - 1 - kt;             // stages after this one
+            const int fly = rem < DEPTH - 1 ? rem : DEPTH - 1;   // stages allowed to stay in flight
+            if (fly >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PCW) : "memory");
+            else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PCW) : "memory");
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PCW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // stage kt landed for every wave; everyone is done with stage kt-1
+            asm volatile("" ::: "memory");
+            if (kt + DEPTH < nk) issue(kt + DEPTH, (kt + DEPTH) % NSTG);
+        } else {
+            buf = kt & 1;
+            if (!(p.dbg & 8)) __syncthreads();           // tile kt landed (vmcnt(0) + barrier); everyone is done with buf^1
+            if (kt + 1 < nk && !(p.dbg & 1)) issue(kt + 1, buf ^ 1);
+        }
         const bf16* a = As + buf * BM * BK;
         const bf16* b = Bs + buf * BN * BK;
         // software-pipelined fragment reads: the ds_read_b128s of sub-step kk+1 are in flight while the MFMAs of
@@ -589,20 +611,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     else gemm_epilogue<2, 2, 1, 1, false>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
-template <int WM, int WN, int TM, int TN, int BK, bool CONV>
+template <int WM, int WN, int TM, int TN, int BK, bool CONV, int NSTG = 2>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
-    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    size_t lds = (size_t)NSTG * (BM + BN) * BK * sizeof(bf16);
+    if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
     static bool attr_done = false;      // > 64 KiB dynamic LDS needs the opt-in attribute
     if (!attr_done && lds > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return 0;
 }
 
@@ -652,7 +675,12 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (cfg == 88 && !gemm_pipe_supported(a)) cfg = 44;
     if (!a.epi && (cfg == 44 || cfg == 42 || cfg == 24)) cfg = 22;
     if (cfg == 88) return launch_gemm_pipe(a, s);
-    switch (cfg) {   // 2-digit codes: 4 waves (2x2), wave tile 32TM x 32TN; 44 / 42 / 24: 16 / 8 / 8 waves of 64x64 wave tiles
+#define GOS(WM, WN, TM, TN, BK, NS) return conv ? launch_cfg<WM, WN, TM, TN, BK, true, NS>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false, NS>(a, s)
+    if (!a.epi && (cfg == 444 || cfg == 445)) cfg = 22;
+    switch (cfg) {
+        case 444: GOS(4, 4, 2, 2, 32, 4);   // 256 x 256, BK = 32, 4 stages (3 in flight, 96 KiB), 128 KiB LDS
+        case 445: GOS(4, 4, 2, 2, 32, 5);   // 5 stages (4 in flight, 128 KiB), 160 KiB LDS
+        case 224: GOS(2, 2, 2, 2, 32, 4);   // 128 x 128, BK = 32, 4 stages (64 KiB LDS like cfg 22, 48 KiB in flight)   // 2-digit codes: 4 waves (2x2), wave tile 32TM x 32TN; 44 / 42 / 24: 16 / 8 / 8 waves of 64x64 wave tiles
         case 44: GO(4, 4, 2, 2, 64);     // 256 x 256 block tile, 128 KiB LDS
         case 42: GO(4, 2, 2, 2, 64);     // 256 x 128
         case 24: GO(2, 4, 2, 2, 64);     // 128 x 256
@@ -663,4 +691,5 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         default: GO(2, 2, 1, 1, 64);
     }
 #undef GO
+#undef GOS
 }
