@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--corr-precision", type=int, default=1, choices=[0, 1],
                     help="0 = fp32 MFMA correlation, 1 = fp32-equivalent bf16x3 split (default)")
     ap.add_argument("--cpu-frames", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="frames of the stream processed per step (time-batched: the SOT step of a frame\n                    depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
+    ap.add_argument("--batch", type=int, default=16, help="frames of the stream processed per step (time-batched: the SOT step of a frame\n                    depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent video streams multiplexed on one GPU (own HIP stream + context each)")
     args = ap.parse_args()
 

@@ -347,18 +347,37 @@ __global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restric
         if (k < K) out[(size_t)k * Q + q] = O[k] / L;
 }
 
-int corr_waves() {   // waves per block of the split kernel (env UNI_CORR_WAVES = 4 | 8 for experiments)
-    static const char* env = getenv("UNI_CORR_WAVES");
-    return env && atoi(env) == 8 ? 8 : 4;
+int corr_slots(int precision) {     // co-resident blocks on the device: 2 x 4-wave blocks (fp32) / 1 x 8-wave block (split) per CU
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return precision ? ncu : 2 * ncu;
 }
+// Split of the reference axis: every block walks rows/ns rows in 32-row tiles; blocks run in rounds of `slots`, so the
+// cost model is rounds x (tiles per split + fixed per-block overhead).  (A fixed ">= 1024 blocks" target gave 4.2 rounds
+// = 5 at 800x1280, 16 % quantisation loss.)
 int pick_nsplit(int R, int Q, int precision = 0) {
-    int nqb = cdiv(Q, precision && corr_waves() == 8 ? QB2 : QB);
+    const int nqb = cdiv(Q, precision ? QB2 : QB);
     static const char* env = getenv("UNI_CORR_BLOCKS");
-    int ns = cdiv(env ? atoi(env) : 1024, nqb);          // aim for >= 1024 blocks (measured, tools/corr_bench.py)
     int maxs = R / 256;               // keep >= 8 tiles per split
-    if (ns > maxs) ns = maxs;
-    if (ns < 1) ns = 1;
-    return ns;
+    if (maxs < 1) maxs = 1;
+    if (env) {
+        int ns = cdiv(atoi(env), nqb);
+        return ns > maxs ? maxs : (ns < 1 ? 1 : ns);
+    }
+    const int slots = corr_slots(precision);
+    int best = 1;
+    long best_cost = -1;
+    for (int ns = 1; ns <= maxs && ns <= 64; ++ns) {
+        const long rounds = cdiv(nqb * ns, slots);
+        const long cost = rounds * (cdiv(cdiv(R, ns), TR) + 4);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+    }
+    return best;
 }
 
 template <int KV>
@@ -369,12 +388,8 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
     const int ns_eff = cdiv(R, rps);   // every split non-empty
     if (precision) {
         size_t lds = (size_t)2 * 3 * TR * CD * sizeof(bf16) + (size_t)2 * KV * TR * sizeof(float);
-        if (corr_waves() == 8)
-            hipLaunchKernelGGL((corr_split_kernel<KV, 8>), dim3(cdiv(Q, 256), ns_eff), dim3(512), lds, s, eref, ecur, v, out,
-                               ws, R, Q, K, ns_eff, rps);
-        else
-            hipLaunchKernelGGL((corr_split_kernel<KV, 4>), dim3(cdiv(Q, 128), ns_eff), dim3(256), lds, s, eref, ecur, v, out,
-                               ws, R, Q, K, ns_eff, rps);
+        hipLaunchKernelGGL((corr_split_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
+                           Q, K, ns_eff, rps);
     } else {
         size_t lds = (size_t)(2 * TR * LDA + 2 * KV * TR) * sizeof(float);
         hipLaunchKernelGGL((corr_f32_kernel<KV>), dim3(cdiv(Q, QB), ns_eff), dim3(256), lds, s, eref, ecur, v, out, ws, R,
