@@ -26,6 +26,7 @@
  *                            condinst/mask_branch.py:77-99,158-162)
  *   uni_condinst_masks      DynamicMaskHead.__call__ + aligned_bilinear(d_rate)
  *                           (condinst/dynamic_mask_head.py:172-225; utils/boxes.py:138-146)
+ *   uni_postprocess         postprocess + torchvision nms/batched_nms (utils/boxes.py:33-77)
  *   uni_prior_pyramid       F.interpolate(coarse, 1/2 | 1/4, bilinear) (unicorn_sot.py:103-105)
  *   uni_label_map_s8        get_label_map + F.interpolate(1/8) (unicorn_sot.py:52-53,128-139)
  *   uni_sample_embeddings   per-box F.grid_sample of the embedding map (evaluators/mot_evaluator.py:1024-1034)
@@ -123,6 +124,17 @@ int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const 
 int uni_condinst_masks(const float* mask_feats, const float* up_masks, const float* params, int ldp,
                        const float* inst_loc, const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate,
                        float* out, void* workspace, size_t workspace_bytes, uni_stream_t stream);
+
+/* Detection post-processing of ONE image on the device (row N1): unicorn/utils/boxes.py:33-77 `postprocess`
+ * (+ torchvision.ops.nms / batched_nms semantics).  pred: (A, ld >= 5+num_classes) decoded [cx,cy,w,h,obj,cls...] fp32,
+ * converted to corners IN PLACE like the reference (:36-39).  Survivors, in descending obj*cls order:
+ * det_out (max_det, 7) rows [x1,y1,x2,y2,obj,cls_conf,cls], keep_idx (max_det) anchor indices, *n_out = row count
+ * (device int32, clamped to max_det).  flags: bit 0 = class-agnostic NMS, bit 1 = boxes are already corners (plain
+ * torchvision-style nms on caller boxes).  workspace >= uni_postprocess_workspace_bytes(A) device bytes. */
+size_t uni_postprocess_workspace_bytes(int A);
+int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
+                    int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* workspace, size_t workspace_bytes,
+                    uni_stream_t stream);
 
 /* ---- low-level building blocks (exported for kernel parity tests) --------------------------------------- */
 /* out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+res).  A: bf16 NHWC map (Hin,Win,Cin) row stride lda.

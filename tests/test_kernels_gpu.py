@@ -352,3 +352,66 @@ def test_condinst_masks(L):
     assert torch.allclose(got4.cpu(), ref4, atol=2e-5)
     assert torch.allclose(got.cpu(), ref, atol=2e-5)
     assert condinst_masks(mf.cuda(), um.cuda(), params[:0].cuda(), loc[:0].cuda(), lvl[:0], 4, 2).shape == (0, 1, 160, 224)
+
+
+def _planted_pred(A, nc, seed, n_clusters=40, per=12):
+    """decoded head output (1, A, 5+nc) with clusters of overlapping high-score boxes (NMS has work to do), exact score
+    ties and a low-score background"""
+    n_clusters = min(n_clusters, A // (2 * per))
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.zeros(1, A, 5 + nc)
+    pred[0, :, 0] = torch.rand(A, generator=g) * 1280
+    pred[0, :, 1] = torch.rand(A, generator=g) * 800
+    pred[0, :, 2:4] = torch.rand(A, 2, generator=g) * 60 + 4
+    pred[0, :, 4] = torch.rand(A, generator=g) * 0.05
+    pred[0, :, 5:] = torch.rand(A, nc, generator=g) * 0.05
+    idx = torch.randperm(A, generator=g)[:n_clusters * per].reshape(n_clusters, per)
+    for c in range(n_clusters):
+        cx, cy = torch.rand(2, generator=g) * torch.tensor([1200.0, 720.0]) + 40
+        w, h = torch.rand(2, generator=g) * 120 + 30
+        for j, a in enumerate(idx[c]):
+            jit = (torch.rand(4, generator=g) - 0.5) * torch.tensor([0.5 * w, 0.5 * h, 0.3 * w, 0.3 * h])
+            pred[0, a, :4] = torch.stack([cx, cy, w, h]) + jit
+            pred[0, a, 4] = 0.5 + 0.5 * torch.rand(1, generator=g)
+            pred[0, a, 5 + int(torch.randint(nc, (1,), generator=g))] = 0.6 + 0.4 * torch.rand(1, generator=g)
+    pred[0, idx[0, 1], 4:] = pred[0, idx[0, 0], 4:]          # an exact score tie between two overlapping boxes
+    return pred
+
+
+@pytest.mark.parametrize("A,nc,agnostic", [(2100, 1, False), (21000, 1, True), (21000, 8, False), (21000, 8, True), (333, 3, False)])
+def test_postprocess_device(L, A, nc, agnostic):
+    """uni_postprocess == the oracle's postprocess (boxes.py:33-77 + torchvision nms semantics): same rows, same order, same
+    anchor indices, and the in-place corner conversion of the input"""
+    from unicorn_amd.ops import postprocess_image
+    pred = _planted_pred(A, nc, seed=A + nc)
+    ref_in = pred.clone()
+    ref_det, ref_idx = uo.postprocess(ref_in, nc, 0.2, 0.45, class_agnostic=agnostic, return_index=True)[0]
+    d = pred.clone().cuda()
+    det, idx = postprocess_image(d[0], nc, 0.2, 0.45, class_agnostic=agnostic)
+    assert ref_det is not None and det is not None and 10 < det.shape[0] < A
+    assert torch.equal(idx.cpu(), ref_idx)
+    assert torch.equal(det.cpu(), ref_det)
+    assert torch.equal(d.cpu()[..., :4], ref_in[..., :4])        # corners written back in place
+
+
+def test_postprocess_device_empty_and_all(L):
+    from unicorn_amd.ops import postprocess_image
+    pred = _planted_pred(500, 2, seed=1)
+    det, idx = postprocess_image(pred.clone().cuda()[0], 2, 1.5, 0.45)           # nothing passes the confidence cut
+    assert det is None and idx is None
+    ref_det, ref_idx = uo.postprocess(pred.clone(), 2, 0.0, 0.45, return_index=True)[0]     # every anchor is a candidate
+    det, idx = postprocess_image(pred.clone().cuda()[0], 2, 0.0, 0.45)
+    assert torch.equal(idx.cpu(), ref_idx) and torch.equal(det.cpu(), ref_det)
+
+
+def test_nms_wrappers(L):
+    from unicorn_amd.utils.boxes import nms, batched_nms
+    g = torch.Generator().manual_seed(4)
+    n = 700
+    xy = torch.rand(n, 2, generator=g) * 300
+    boxes = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 80 + 5], 1)
+    scores = torch.rand(n, generator=g)
+    cls = torch.randint(0, 4, (n,), generator=g)
+    assert torch.equal(nms(boxes.cuda(), scores.cuda(), 0.5).cpu(), uo.nms(boxes, scores, 0.5))
+    assert torch.equal(batched_nms(boxes.cuda(), scores.cuda(), cls.cuda(), 0.5).cpu(), uo.batched_nms(boxes, scores, cls, 0.5))
+    assert nms(boxes[:0].cuda(), scores[:0].cuda(), 0.5).numel() == 0

@@ -123,6 +123,14 @@ int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const 
     UNI_REQUIRE(embed_nhwc && (n == 0 || (boxes_xyxy && out)), "sample_embeddings: NULL argument");
     API(launch_sample_embed(embed_nhwc, H8, W8, C, boxes_xyxy, ld_boxes, n, stride, out, S(stream)));
 }
+size_t uni_postprocess_workspace_bytes(int A) { return postprocess_workspace_bytes(A); }
+int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags, int max_det,
+                    float* det_out, int32_t* keep_idx, int32_t* n_out, void* workspace, size_t workspace_bytes,
+                    uni_stream_t stream) {
+    UNI_REQUIRE(n_out && (A == 0 || (pred && workspace)) && (max_det == 0 || (det_out && keep_idx)), "postprocess: NULL argument");
+    API(launch_postprocess(pred, A, ld, num_classes, conf_thre, nms_thre, flags, max_det, det_out, keep_idx, n_out,
+                           workspace, workspace_bytes, S(stream)));
+}
 int uni_condinst_masks(const float* mask_feats, const float* up_masks, const float* params, int ldp, const float* inst_loc,
                        const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate, float* out, void* workspace,
                        size_t workspace_bytes, uni_stream_t stream) {

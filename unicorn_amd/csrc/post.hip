@@ -1,0 +1,216 @@
+// N1: detection post-processing on the device, one image per call --
+// unicorn/utils/boxes.py:33-77 (`postprocess`): cxcywh -> corners IN PLACE (:36-39), class max + `obj*cls >= conf_thre`
+// filter (:49-55), torchvision `nms` / `batched_nms` (:58-69; greedy, descending score, suppress IoU > thr; batched = per
+// class through the coordinate offset `idx * (max_coordinate + 1)`), rows [x1,y1,x2,y2,obj,cls_conf,cls] of the survivors
+// in descending-score order.  Everything stays on the device (the reference syncs on every boolean-mask index and inside
+// torchvision's NMS); the caller reads back one int32 (the row count) because the result shape is data dependent.
+//
+// Integer / order semantics are exact: candidates keep their anchor order, the sort is the stable descending argsort
+// (rank by counting, ties by anchor index), IoU is evaluated with the same fp32 operation order as the oracle with
+// contraction disabled, so kept indices are bit-identical to the CPU restatement.
+#include "kernels.h"
+
+namespace {
+constexpr int PT = 256;
+
+struct PostWs {                 // layout of the caller-provided workspace
+    int* n_cand;                // [1]
+    unsigned* maxc_key;         // [1] order-preserving key of the running max coordinate of the candidates
+    float* score;               // [A]  obj * cls_conf for candidates, -inf otherwise
+    float* cconf;               // [A]
+    int* cls;                   // [A]
+    int* order;                 // [A]  anchor index of the r-th best candidate
+    float* sbox;                // [A][4] class-offset boxes in sorted order
+    unsigned long long* mask;   // [A][ceil(A/64)] suppression bits (allocated for n_cand rows only when called)
+};
+
+__device__ __forceinline__ unsigned fkey(float f) {     // monotone float -> unsigned
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__global__ void post_prep_kernel(float* __restrict__ pred, int A, int ld, int nc, float conf_thre, int corners, float* score,
+                                 float* cconf, int* cls, int* n_cand, unsigned* maxc_key) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    float* p = pred + (size_t)a * ld;
+    float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    if (!corners) {                                      // boxes.py:36-39, in place
+        const float cx = x1, cy = y1, w = x2, h = y2;
+        x1 = cx - w / 2; y1 = cy - h / 2; x2 = cx + w / 2; y2 = cy + h / 2;
+        p[0] = x1; p[1] = y1; p[2] = x2; p[3] = y2;
+    }
+    float best = p[5];
+    int bi = 0;
+    for (int c = 1; c < nc; ++c) {                       // torch.max: first maximal index
+        const float v = p[5 + c];
+        if (v > best) { best = v; bi = c; }
+    }
+    const float sc = p[4] * best;
+    const bool keep = sc >= conf_thre;                   // boxes.py:52
+    score[a] = keep ? sc : -INFINITY;
+    cconf[a] = best;
+    cls[a] = bi;
+    if (keep) {
+        atomicAdd(n_cand, 1);
+        const float m = fmaxf(fmaxf(x1, y1), fmaxf(x2, y2));
+        atomicMax(maxc_key, fkey(m));
+    }
+}
+
+// stable descending rank among the candidates: rank(a) = #{b : s_b > s_a or (s_b == s_a and b < a)}
+__global__ void post_rank_kernel(const float* __restrict__ score, int A, int* __restrict__ order) {
+    __shared__ float tile[PT];
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const float sa = a < A ? score[a] : -INFINITY;
+    const bool cand = sa > -INFINITY;
+    int rank = 0;
+    for (int b0 = 0; b0 < A; b0 += PT) {
+        __syncthreads();
+        tile[threadIdx.x] = (b0 + threadIdx.x < A) ? score[b0 + threadIdx.x] : -INFINITY;
+        __syncthreads();
+        if (cand) {
+            const int lim = min(PT, A - b0);
+            for (int j = 0; j < lim; ++j) {
+                const float sb = tile[j];
+                rank += (sb > sa) || (sb == sa && b0 + j < a);
+            }
+        }
+    }
+    if (cand) order[rank] = a;
+}
+
+__global__ void post_sortbox_kernel(const float* __restrict__ pred, int ld, const int* __restrict__ order,
+                                    const int* __restrict__ cls, const int* n_cand, const unsigned* maxc_key,
+                                    int class_agnostic, float* __restrict__ sbox) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_cand) return;
+    const int a = order[r];
+    const float* p = pred + (size_t)a * ld;
+    {
+#pragma clang fp contract(off)
+        // torchvision batched_nms coordinate trick: off = idx * (max_coordinate + 1), fp32, no FMA
+        const float off = class_agnostic ? 0.f : (float)cls[a] * (fkey_inv(*maxc_key) + 1.f);
+        sbox[4 * r + 0] = p[0] + off;
+        sbox[4 * r + 1] = p[1] + off;
+        sbox[4 * r + 2] = p[2] + off;
+        sbox[4 * r + 3] = p[3] + off;
+    }
+}
+
+// bit (i, j) = IoU(box_i, box_j) > thr for j > i; one 64 x 64 tile per block
+__global__ void post_iou_kernel(const float* __restrict__ sbox, const int* n_cand, float thr, int words,
+                                unsigned long long* __restrict__ mask) {
+#pragma clang fp contract(off)                            // same fp32 operation order as the oracle, no FMA
+    const int n = *n_cand;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    if (i0 >= n || j0 >= n || j0 + 63 < i0) return;
+    __shared__ float cb[64][4];
+    const int t = threadIdx.x;
+    if (j0 + t < n) {
+        cb[t][0] = sbox[4 * (j0 + t)]; cb[t][1] = sbox[4 * (j0 + t) + 1];
+        cb[t][2] = sbox[4 * (j0 + t) + 2]; cb[t][3] = sbox[4 * (j0 + t) + 3];
+    }
+    __syncthreads();
+    const int i = i0 + t;
+    if (i >= n) return;
+    const float x1 = sbox[4 * i], y1 = sbox[4 * i + 1], x2 = sbox[4 * i + 2], y2 = sbox[4 * i + 3];
+    const float ai = (x2 - x1) * (y2 - y1);
+    unsigned long long bits = 0ull;
+    const int lim = min(64, n - j0);
+    for (int j = 0; j < lim; ++j) {
+        if (j0 + j <= i) continue;
+        const float lx = fmaxf(x1, cb[j][0]), ly = fmaxf(y1, cb[j][1]);
+        const float rx = fminf(x2, cb[j][2]), ry = fminf(y2, cb[j][3]);
+        const float w = fmaxf(rx - lx, 0.f), h = fmaxf(ry - ly, 0.f);
+        const float inter = w * h;
+        const float aj = (cb[j][2] - cb[j][0]) * (cb[j][3] - cb[j][1]);
+        const float iou = inter / (ai + aj - inter);
+        if (iou > thr) bits |= 1ull << j;
+    }
+    mask[(size_t)i * words + blockIdx.x] = bits;
+}
+
+// greedy sweep (one block): walk the candidates in score order, OR the rows of the survivors into the removed set
+__global__ __launch_bounds__(1024) void post_sweep_kernel(const float* __restrict__ pred, int ld, const int* __restrict__ order,
+                                                          const float* __restrict__ cconf, const int* __restrict__ cls,
+                                                          const int* n_cand, int words, const unsigned long long* __restrict__ mask,
+                                                          int max_det, float* __restrict__ det, int* __restrict__ keep_idx,
+                                                          int* __restrict__ n_out) {
+    extern __shared__ unsigned long long removed[];      // [words]
+    __shared__ int nk;
+    const int n = *n_cand;
+    const int nw = (n + 63) / 64;
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
+    if (threadIdx.x == 0) nk = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;     // uniform
+        if (!dead) {
+            if (threadIdx.x == 0) {
+                const int k = nk;
+                if (k < max_det) {
+                    const int a = order[i];
+                    const float* p = pred + (size_t)a * ld;
+                    float* d = det + (size_t)k * 7;
+                    d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3]; d[4] = p[4];
+                    d[5] = cconf[a]; d[6] = (float)cls[a];
+                    keep_idx[k] = a;
+                }
+                nk = k + 1;
+            }
+            const unsigned long long* row = mask + (size_t)i * words;
+            for (int w = (i >> 6) + threadIdx.x; w < nw; w += blockDim.x) removed[w] |= row[w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = nk < max_det ? nk : max_det;
+}
+}  // namespace
+
+size_t postprocess_workspace_bytes(int A) {
+    const size_t words = (size_t)(A + 63) / 64;
+    return 256 + (size_t)A * (4 + 4 + 4 + 4 + 16) + (size_t)A * words * 8 + 256;
+}
+
+int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
+                       int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+    UNI_REQUIRE(A >= 0 && num_classes >= 1 && ld >= 5 + num_classes && max_det >= 0, "postprocess: bad shape A=%d nc=%d ld=%d",
+                A, num_classes, ld);
+    UNI_REQUIRE(ws_bytes >= postprocess_workspace_bytes(A), "postprocess: workspace too small");
+    if (A == 0) {
+        UNI_CHECK_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), s));
+        return 0;
+    }
+    char* base = reinterpret_cast<char*>(ws);
+    PostWs w;
+    w.n_cand = reinterpret_cast<int*>(base);
+    w.maxc_key = reinterpret_cast<unsigned*>(base + 4);
+    char* q = base + 256;
+    w.score = reinterpret_cast<float*>(q); q += (size_t)A * 4;
+    w.cconf = reinterpret_cast<float*>(q); q += (size_t)A * 4;
+    w.cls = reinterpret_cast<int*>(q); q += (size_t)A * 4;
+    w.order = reinterpret_cast<int*>(q); q += (size_t)A * 4;
+    w.sbox = reinterpret_cast<float*>(q); q += (size_t)A * 16;
+    q = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(q) + 7) & ~uintptr_t(7));
+    w.mask = reinterpret_cast<unsigned long long*>(q);
+    const int words = (A + 63) / 64;
+    UNI_CHECK_HIP(hipMemsetAsync(base, 0, 8, s));       // n_cand = 0, maxc_key = 0 (below every real key)
+    const int nb = cdiv(A, PT);
+    hipLaunchKernelGGL(post_prep_kernel, dim3(nb), dim3(PT), 0, s, pred, A, ld, num_classes, conf_thre, (flags >> 1) & 1, w.score, w.cconf, w.cls,
+                       w.n_cand, w.maxc_key);
+    hipLaunchKernelGGL(post_rank_kernel, dim3(nb), dim3(PT), 0, s, w.score, A, w.order);
+    hipLaunchKernelGGL(post_sortbox_kernel, dim3(nb), dim3(PT), 0, s, pred, ld, w.order, w.cls, w.n_cand, w.maxc_key,
+                       flags & 1, w.sbox);
+    // the grid covers the worst case (every anchor a candidate); tiles beyond n_cand return immediately
+    hipLaunchKernelGGL(post_iou_kernel, dim3(words, words), dim3(64), 0, s, w.sbox, w.n_cand, nms_thre, words, w.mask);
+    const size_t lds = (size_t)words * 8;
+    hipLaunchKernelGGL(post_sweep_kernel, dim3(1), dim3(1024), lds, s, pred, ld, w.order, w.cconf, w.cls, w.n_cand, words, w.mask,
+                       max_det, det_out, keep_idx, n_out);
+    return 0;
+}

@@ -115,3 +115,32 @@ def condinst_masks(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_
                                            up_rate, d_rate, L.ptr(out), L.ptr(ws), ws.numel() * 4, L.stream_ptr()),
                 "uni_condinst_masks")
     return out
+
+
+_post_ws = {}
+
+
+def postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnostic=False, precornered=False):
+    """unicorn/utils/boxes.py:33-77 for ONE image on the device (uni_postprocess): image_pred (A, 5+nc) decoded cxcywh fp32,
+    converted to corners in place (precornered=True: boxes are already xyxy).  Returns (det (M,7), anchor indices (M,) int64) or (None, None).  The only host sync is
+    the read-back of M (the output shape is data dependent)."""
+    _need_cuda(image_pred)
+    if image_pred.dtype != torch.float32 or image_pred.stride(-1) != 1:
+        raise UnicornHipError("postprocess_image: needs a float32 (A, 5+nc) tensor with unit inner stride")
+    A, ld = image_pred.shape[0], image_pred.stride(0) if image_pred.shape[0] > 1 else image_pred.shape[1]
+    dev = image_pred.device
+    need = L.lib().uni_postprocess_workspace_bytes(A)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _post_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1), device=dev, dtype=torch.uint8)
+        _post_ws[key] = ws
+    det = torch.empty((max(A, 1), 7), device=dev, dtype=torch.float32)
+    keep = torch.empty((max(A, 1),), device=dev, dtype=torch.int32)
+    n = torch.zeros((1,), device=dev, dtype=torch.int32)
+    L.check(L.lib().uni_postprocess(L.ptr(image_pred), A, ld, num_classes, float(conf_thre), float(nms_thre),
+                                    int(bool(class_agnostic)) | (2 if precornered else 0), A, L.ptr(det), L.ptr(keep), L.ptr(n), L.ptr(ws), ws.numel(), L.stream_ptr()), "uni_postprocess")
+    m = int(n.item())
+    if m == 0:
+        return None, None
+    return det[:m], keep[:m].long()

@@ -1,33 +1,28 @@
 """Post-processing with the reference's signatures (unicorn/utils/boxes.py:33-152).
 
-Row N1 of SURVEY.md §8f ("next"): host-side glue on device tensors.  NMS follows torchvision semantics (greedy,
-descending score, suppress IoU > thr; batched = per-class via the coordinate-offset trick), evaluated as one
-IoU matrix on the GPU plus a sequential sweep over the (few hundred) candidates.
+Row N1 of SURVEY.md §8f: `postprocess` / `postprocess_inst` run on the device through `uni_postprocess` (post.hip):
+corners in place, class max + confidence filter, torchvision nms / batched_nms semantics (greedy, descending score, suppress
+IoU > thr; batched = per class via the coordinate-offset trick), survivors in descending-score order.  One int32 is read
+back per image (the row count).  `nms` / `batched_nms` below are the stand-alone torchvision-style entry points (used by
+callers that bring their own boxes); they share the same kernels.
 """
 import torch
 
-from ..ops import condinst_masks
+from ..ops import condinst_masks, postprocess_image
 
 
 def nms(boxes, scores, thr):
+    """torchvision.ops.nms on the device: kept indices in descending-score order."""
     n = boxes.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.long, device=boxes.device)
-    order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order]
-    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    lt = torch.max(b[:, None, :2], b[None, :, :2])
-    rb = torch.min(b[:, None, 2:], b[None, :, 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    over = (inter / (area[:, None] + area[None] - inter) > thr).cpu()      # one D2H copy
-    keep, sup = [], torch.zeros(n, dtype=torch.bool)
-    for i in range(n):
-        if sup[i]:
-            continue
-        keep.append(i)
-        sup |= over[i]
-    return order[torch.tensor(keep, dtype=torch.long, device=boxes.device)]
+    # rows [x1,y1,x2,y2, obj = score, cls_conf = 1]: class-agnostic pass without a confidence cut on pre-cornered boxes
+    pred = torch.empty((n, 6), device=boxes.device, dtype=torch.float32)
+    pred[:, :4] = boxes.float()
+    pred[:, 4] = scores.float()
+    pred[:, 5] = 1.0
+    det, keep = postprocess_image(pred, 1, float("-inf"), thr, class_agnostic=True, precornered=True)
+    return keep if keep is not None else torch.empty((0,), dtype=torch.long, device=boxes.device)
 
 
 def batched_nms(boxes, scores, idxs, thr):
@@ -48,38 +43,27 @@ def _corners_(prediction):
 
 
 def _select(image_pred, num_classes, conf_thre, nms_thre, class_agnostic):
-    class_conf, class_pred = torch.max(image_pred[:, 5:5 + num_classes], 1, keepdim=True)
-    conf_mask = image_pred[:, 4] * class_conf.squeeze(1) >= conf_thre
-    det = torch.cat((image_pred[:, :5], class_conf, class_pred.float()), 1)[conf_mask]
-    if det.shape[0] == 0:
-        return None, None, conf_mask
-    sc = det[:, 4] * det[:, 5]
-    keep = nms(det[:, :4], sc, nms_thre) if class_agnostic else batched_nms(det[:, :4], sc, det[:, 6], nms_thre)
-    return det[keep], keep, conf_mask
+    """one image: (det (M,7) | None, anchor indices (M,) | None); image_pred is converted to corners in place"""
+    return postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnostic)
 
 
 def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
-    prediction = _corners_(prediction)
     return [_select(ip, num_classes, conf_thre, nms_thre, class_agnostic)[0] for ip in prediction]
 
 
 def postprocess_inst(prediction, locations, dynamic_params, fpn_levels, mask_feats, mask_head, num_classes, conf_thre=0.7,
                      nms_thre=0.45, class_agnostic=False, d_rate=4, up_masks=None):
-    prediction = _corners_(prediction)
     output, output_mask = [], []
     for i, ip in enumerate(prediction):
-        det, keep, conf_mask = _select(ip, num_classes, conf_thre, nms_thre, class_agnostic)
+        det, idx = _select(ip, num_classes, conf_thre, nms_thre, class_agnostic)
         if det is None:
             output.append(None)
             output_mask.append(None)
             continue
-        cm_cpu = conf_mask.cpu()
-        locs = locations[conf_mask][keep]
-        dps = dynamic_params[i][conf_mask][keep]
-        lvls = fpn_levels[i][cm_cpu][keep.cpu()]
         um = up_masks[0:1] if (up_masks is not None and len(up_masks) == 1) else (None if up_masks is None else up_masks[i:i + 1])
-        # fused DynamicMaskHead + aligned_bilinear(d_rate) (boxes.py:138-146)
-        masks = condinst_masks(mask_feats[i:i + 1], um, dps, locs, lvls, mask_head.up_rate, d_rate)
+        # fused DynamicMaskHead + aligned_bilinear(d_rate) (boxes.py:138-146) on the surviving anchors
+        masks = condinst_masks(mask_feats[i:i + 1], um, dynamic_params[i][idx], locations[idx], fpn_levels[i][idx],
+                               mask_head.up_rate, d_rate)
         output.append(det)
         output_mask.append(masks)
     return output, output_mask
