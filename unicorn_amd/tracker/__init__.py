@@ -1,1 +1,2 @@
 from .unicorn_sot import UnicornSOTTrack  # noqa: F401
+from .quasi_dense_embed_tracker import QuasiDenseEmbedTracker  # noqa: F401
