@@ -26,20 +26,34 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
-// GELU for bf16-rounded outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, ~3x fewer VALU ops than erff);
-// the exact-fp32 precision mode keeps erff (act_apply).
-__device__ __forceinline__ float act_apply_fast(float x, int act) {
-    if (act == ACT_GELU) {
+// Activations for the bf16 path with the activation kind as a COMPILE-TIME constant (branch-free inner loops).
+// GELU: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, ~3x fewer VALU ops than erff); sigmoid / SiLU with the
+// hardware reciprocal (1 ulp) instead of the IEEE division sequence.  The exact-fp32 precision mode keeps act_apply.
+template <int ACT>
+__device__ __forceinline__ float act_fast(float x) {
+    if (ACT == ACT_GELU) {
         const float z = fabsf(x) * 0.70710678118654752f;
         const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
         float q = fmaf(1.061405429f, t, -1.453152027f);
         q = fmaf(q, t, 1.421413741f);
         q = fmaf(q, t, -0.284496736f);
         q = fmaf(q, t, 0.254829592f);
-        const float e = 1.f - q * t * __expf(-z * z);       // erf(|x|/sqrt2)
+        const float e = 1.f - q * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erf(|x|/sqrt2)
         return 0.5f * x * (1.f + copysignf(e, x));
     }
-    return act_apply(x, act);
+    if (ACT == ACT_RELU) return fmaxf(x, 0.f);
+    if (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    if (ACT == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return x;
+}
+__device__ __forceinline__ float act_apply_fast(float x, int act) {
+    switch (act) {
+        case ACT_GELU: return act_fast<ACT_GELU>(x);
+        case ACT_RELU: return act_fast<ACT_RELU>(x);
+        case ACT_SILU: return act_fast<ACT_SILU>(x);
+        case ACT_SIGMOID: return act_fast<ACT_SIGMOID>(x);
+        default: return x;
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -24,6 +24,7 @@
 //  * Blocks are remapped so each XCD (private 4 MiB L2) owns a contiguous range of M panels.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 __device__ u32x4 g_zero_page = {0u, 0u, 0u, 0u};
 
@@ -49,7 +50,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool STATS>
 __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                   int lane, char* smem) {
     constexpr int CW = 32 * TN;            // wave tile width in channels
@@ -60,26 +61,38 @@ __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&ac
     __syncthreads();                       // all waves are done with the last operand tile
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // phase A: bias + activation in the MFMA layout, float4 chunks to LDS [row fr][chunk ^ (fr & 7)]
+        // phase A: bias + activation in the MFMA layout, float4 chunks to LDS [row fr][chunk ^ (fr & 7)].  The activation
+        // kind is dispatched ONCE per slab (uniform branch) so the 32-element loops are branch-free; the column window
+        // (act_col0) is a select.
+        auto phase_a = [&](auto act_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = nw0 + j * 32 + 8 * g + 4 * fh;
-                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if (col < p.N) {
-                    if (p.bias) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-                        v += b4;
+                for (int g = 0; g < 4; ++g) {
+                    const int col = nw0 + j * 32 + 8 * g + 4 * fh;
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
+                    if (ACT != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = act_fast<ACT>(v[e]);
+                            v[e] = (col + e >= p.act_col0) ? a : v[e];
+                        }
                     }
-                    if (p.act != ACT_NONE) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (col + e >= p.act_col0) ? act_apply_fast(v[e], p.act) : v[e];
-                    }
+                    const int c = j * 8 + 2 * g + fh;
+                    *reinterpret_cast<f32x4*>(st + fr * CW + ((c ^ (fr & 7)) << 2)) = v;
                 }
-                const int c = j * 8 + 2 * g + fh;
-                *reinterpret_cast<f32x4*>(st + fr * CW + ((c ^ (fr & 7)) << 2)) = v;
             }
+        };
+        if (STATS) {   // GroupNorm-statistics GEMMs never carry an activation (it follows the normalisation; launch_gemm checks)
+            phase_a(std::integral_constant<int, ACT_NONE>{});
+        } else switch (p.act) {
+            case ACT_GELU: phase_a(std::integral_constant<int, ACT_GELU>{}); break;
+            case ACT_RELU: phase_a(std::integral_constant<int, ACT_RELU>{}); break;
+            case ACT_SILU: phase_a(std::integral_constant<int, ACT_SILU>{}); break;
+            case ACT_SIGMOID: phase_a(std::integral_constant<int, ACT_SIGMOID>{}); break;
+            default: phase_a(std::integral_constant<int, ACT_NONE>{}); break;
         }
         wave_lds_fence();
         // phase B: whole rows out
@@ -137,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     const bool vec_ok = (p.N & 3) == 0;
     // the 8/16-wave tiles (register budget 128-256) are only launched with staged stores; the direct path is compiled out
     constexpr bool ONLY_STAGED = WM * WN > 4;
-    if (ONLY_STAGED || p.epi) gemm_store_staged<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, smem);
+    if (ONLY_STAGED || p.epi) gemm_store_staged<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, smem);
 #pragma unroll
     for (int i = 0; i < ((ONLY_STAGED || p.epi) ? 0 : TM); ++i) {
         const int row = m0 + wm * 32 * TM + i * 32 + fr;
@@ -648,6 +661,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     }
     if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 4096 && a.Mper / a.Wout < 4096, "gemm: conv K mismatch / map too large");
     if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64, "gemm: cpg=%d unsupported", a.cpg);
+    if (a.stats) UNI_REQUIRE(a.act == ACT_NONE, "gemm: GroupNorm statistics and an epilogue activation are exclusive");
     // tile choice (measured on MI355X, tools/gemm_bench.py at batch-1 and batch-8 row counts): the K loop is bound by
     // the global->LDS fill rate, so the biggest block tile that still yields >= ~1.5 blocks per CU wins (256x256,
     // 16 waves); small problems want >= ~400 blocks of a smaller tile; implicit convs amortise their gather

@@ -56,9 +56,7 @@ __device__ __forceinline__ void wave_fence() {
 
 template <int ACT>
 __device__ __forceinline__ float act_ct(float x) {
-    if (ACT == ACT_GELU) return act_apply_fast(x, ACT_GELU);
-    if (ACT == ACT_RELU) return fmaxf(x, 0.f);
-    return x;
+    return act_fast<ACT>(x);
 }
 
 // phase A of slab I: bias + activation in the MFMA layout, float4 chunks to the wave's LDS tile [row][chunk ^ (row & 7)]
