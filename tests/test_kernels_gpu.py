@@ -97,7 +97,7 @@ def test_gemm_conv(L, cfg, case):
         assert torch.allclose(s_got, s_ref, rtol=1e-3, atol=1e-2), (s_got - s_ref).abs().max()
 
 
-@pytest.mark.parametrize("cfg", [88, 44, 444, 445, 224, 0])
+@pytest.mark.parametrize("cfg", [144, 88, 44, 444, 445, 224, 0])
 @pytest.mark.parametrize("case", [
     # (M, N, K, act, res, outF, outB): > 256 tiles of 256x128 so persistent blocks walk several tiles
     (70001, 256, 64, 2, False, False, True),      # one K step per tile (drain slices outnumber K steps), GELU, bf16 out

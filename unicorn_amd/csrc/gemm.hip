@@ -686,6 +686,10 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         else cfg = b21 >= 400 ? 21 : 11;
     }
 #define GO(WM, WN, TM, TN, BK) return conv ? launch_cfg<WM, WN, TM, TN, BK, true>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false>(a, s)
+    // plain GEMMs that would take the 256x256 tile go to the persistent variant (gemm_p44.hip): -5..-20 % on the MLP shapes
+    if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_p44_supported(a) && !getenv("UNI_NO_P44")) cfg = 144;
+    if (cfg == 144 && !gemm_p44_supported(a)) cfg = 44;
+    if (cfg == 144) return launch_gemm_p44(a, s);
     if (cfg == 88 && !gemm_pipe_supported(a)) cfg = 44;
     if (!a.epi && (cfg == 44 || cfg == 42 || cfg == 24)) cfg = 22;
     if (cfg == 88) return launch_gemm_pipe(a, s);

@@ -25,7 +25,9 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_gemm_pipe(const GemmArgs& a, hipStream_t s);
-bool gemm_pipe_supported(const GemmArgs& a);   // gemm_pipe.hip: persistent 256x128 tiles, drain overlapped with the next tile
+bool gemm_pipe_supported(const GemmArgs& a);
+int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persistent 256x256 tiles, next tile prefetched before the drain
+bool gemm_p44_supported(const GemmArgs& a);   // gemm_pipe.hip: persistent 256x128 tiles, drain overlapped with the next tile
 
 // ---------------------------------------------------------------- norm.hip
 // Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.
