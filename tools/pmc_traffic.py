@@ -10,7 +10,7 @@ for tag, d in (("fetch", sys.argv[1]), ("write", sys.argv[2])):
             if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            cls = "gemm_bf16_kernel" if "gemm_bf16_kernel" in name else name[:40]
+            cls = "gemm_bf16_kernel" if "gemm_bf16" in name else name[:40]   # incl. the persistent gemm_bf16_p44 / _pipe kernels
             acc[cls][0] += float(r["Counter_Value"]) * 1024.0 * (2.0 if tag == "fetch" else 1.0)
             acc[cls][1] += 1
     for k, (b, n) in acc.items():
