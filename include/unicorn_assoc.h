@@ -45,6 +45,30 @@ int uni_qd_match(uni_qd* t, const float* bboxes, const int64_t* labels, const fl
 int64_t uni_qd_num_tracklets(const uni_qd* t);
 int uni_qd_alive(const uni_qd* t, int64_t* ids_out, int capacity);
 
+/* ---- ByteTrack (unicorn/tracker/byte_tracker.py:142-337 BYTETracker + STrack, matching.py:39-51,75-91,173-181,
+ * kalman_filter.py:40-225, basetrack.py).  The drivers build it as BYTETracker(args, frame_rate=30) and call
+ * update(output_results, img_info, img_size) once per frame (unicorn/evaluators/mot_evaluator.py:149,186,208-212). */
+typedef struct uni_byte uni_byte;
+typedef struct {
+    float track_thresh;   /* args.track_thresh */
+    int32_t track_buffer; /* args.track_buffer */
+    float match_thresh;   /* args.match_thresh */
+    int32_t mot20;        /* args.mot20 */
+    int32_t frame_rate;   /* constructor argument, default 30 */
+} uni_byte_cfg;
+uni_byte* uni_byte_create(const uni_byte_cfg* cfg);
+void uni_byte_destroy(uni_byte* t);
+/* BYTETracker.update (:156-293).  dets: float32 (n, ld) rows, ld == 5: [x1,y1,x2,y2,score], ld >= 6: score = c4*c5 (:165-171),
+ * in network-input coordinates; divided by min(size_h/img_h, size_w/img_w) like the reference (:172-174).
+ * Outputs (capacity cap rows): activated tracks in the reference's list order: tlwh (m,4) float64, score (m) float32,
+ * track_id (m), *n_out = m (clamped to cap).  Returns 0 or a negative code. */
+int uni_byte_update(uni_byte* t, const float* dets, int n, int ld, double img_h, double img_w, double size_h, double size_w,
+                    int cap, double* out_tlwh, float* out_score, int64_t* out_id, int* n_out);
+/* BaseTrack._count (a process-wide id counter in the reference, basetrack.py:12,35-38) and BaseTrack.clean_id() */
+int64_t uni_byte_id_count(void);
+void uni_byte_clean_id(void);
+int uni_byte_lost(const uni_byte* t, int64_t* ids_out, int capacity);   /* ids of self.lost_stracks (parity tests) */
+
 #ifdef __cplusplus
 }
 #endif

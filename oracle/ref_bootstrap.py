@@ -92,6 +92,22 @@ def _install_stubs():
     tv = _mod("torchvision")
     tv.ops = _mod("torchvision.ops", nms=nms, batched_nms=batched_nms, box_iou=box_iou)
 
+    # ByteTrack's third-party solvers (absent offline): restated from their published semantics in oracle/bytetrack_oracle.py
+    def _lapjv(cost, extend_cost=True, cost_limit=float("inf")):
+        import bytetrack_oracle as _bo
+        return _bo.lapjv(cost, extend_cost, cost_limit)
+
+    def _bbox_overlaps(a, b):
+        import bytetrack_oracle as _bo
+        return _bo.bbox_overlaps(a, b)
+
+    _mod("lap", lapjv=_lapjv)
+    _mod("cython_bbox", bbox_overlaps=_bbox_overlaps)
+    import numpy as _np
+    for _alias, _t in (("float", float), ("int", int), ("bool", bool)):     # removed in numpy >= 1.24, used by the reference
+        if not hasattr(_np, _alias):
+            setattr(_np, _alias, _t)
+
     _mod("thop", profile=lambda *a, **k: (0, 0))
     cv2 = _mod("cv2", setNumThreads=lambda n: None)
     cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda b: None)
@@ -132,8 +148,6 @@ def _install_stubs():
     pc.mask = _mod("pycocotools.mask")
     pc.coco = _mod("pycocotools.coco", COCO=object)
     pc.cocoeval = _mod("pycocotools.cocoeval", COCOeval=object)
-    _mod("lap")
-    _mod("cython_bbox", bbox_overlaps=lambda *a, **k: None)
     _mod("motmetrics")
     _mod("tabulate", tabulate=lambda *a, **k: "") if "tabulate" not in sys.modules else None
 

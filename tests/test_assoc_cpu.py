@@ -81,3 +81,80 @@ def test_native_errors_and_edges():
         trk.match(torch.zeros(2, 4), torch.zeros(2, dtype=torch.long), torch.zeros(2, 16), 3)
     with pytest.raises(AssertionError):
         QuasiDenseEmbedTracker(match_metric="l2")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ByteTrack
+# ---------------------------------------------------------------------------------------------------------------------
+import types  # noqa: E402
+
+import bytetrack_oracle as bo  # noqa: E402
+from unicorn_amd.tracker import byte_tracker as nbt  # noqa: E402
+
+BGOLD = np.load(os.path.join(ROOT, "tests", "golden", "byte_sequence.npz"))
+BCASES = [("default", dict(track_thresh=0.6, track_buffer=30, match_thresh=0.9, mot20=False), 0, 12),
+          ("mot20", dict(track_thresh=0.5, track_buffer=10, match_thresh=0.8, mot20=True), 1, 12),
+          ("crowded", dict(track_thresh=0.6, track_buffer=30, match_thresh=0.9, mot20=False), 2, 30)]
+
+
+def test_byte_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "unicorn_assoc.h")).read()
+    names = set(re.findall(r"\b(uni_byte_[a-z_]+)\s*\(", hdr))
+    assert {"uni_byte_create", "uni_byte_destroy", "uni_byte_update", "uni_byte_id_count", "uni_byte_clean_id", "uni_byte_lost"} <= names
+    for n in names:
+        assert hasattr(assoc_lib(), n), n
+
+
+@pytest.mark.parametrize("name,kw,seed,nobj", BCASES)
+def test_byte_oracle_matches_reference_golden(name, kw, seed, nobj):
+    st = bo.ByteState(**kw)
+    frames, info, size = bo.synth_detections(seed=seed, n_obj=nobj)
+    for f, d in enumerate(frames):
+        res = bo.byte_update(st, d, info, size)
+        assert np.array_equal(np.array([t.track_id for t in res], dtype=np.int64), BGOLD["%s/%d/ids" % (name, f)]), f
+        assert np.allclose(np.array([t.tlwh for t in res]).reshape(-1, 4), BGOLD["%s/%d/tlwh" % (name, f)], rtol=0, atol=1e-9), f
+        assert np.array_equal(np.array([t.score for t in res], dtype=np.float32), BGOLD["%s/%d/score" % (name, f)]), f
+    assert st.count == int(BGOLD[name + "/count"])
+    assert sorted(t.track_id for t in st.lost) == BGOLD[name + "/lost"].tolist()
+
+
+@pytest.mark.parametrize("name,kw,seed,nobj", BCASES)
+def test_byte_native_matches_reference_golden(name, kw, seed, nobj):
+    nbt.clean_id()
+    trk = nbt.BYTETracker(types.SimpleNamespace(**kw), frame_rate=30)
+    frames, info, size = bo.synth_detections(seed=seed, n_obj=nobj)
+    for f, d in enumerate(frames):
+        res = trk.update(d.copy(), info, size)
+        assert np.array_equal(np.array([t.track_id for t in res], dtype=np.int64), BGOLD["%s/%d/ids" % (name, f)]), f
+        assert np.allclose(np.array([t.tlwh for t in res]).reshape(-1, 4), BGOLD["%s/%d/tlwh" % (name, f)], rtol=0, atol=1e-8), f
+        assert np.array_equal(np.array([t.score for t in res], dtype=np.float32), BGOLD["%s/%d/score" % (name, f)]), f
+    assert nbt.id_count() == int(BGOLD[name + "/count"])
+    assert sorted(trk.lost_ids) == BGOLD[name + "/lost"].tolist()
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7, 8])
+def test_byte_native_matches_oracle_more_sequences(seed):
+    kw = dict(track_thresh=0.55, track_buffer=20, match_thresh=0.85, mot20=bool(seed & 1))
+    nbt.clean_id()
+    st, trk = bo.ByteState(**kw), nbt.BYTETracker(types.SimpleNamespace(**kw), frame_rate=25)
+    st.max_time_lost = int(25 / 30.0 * 20)
+    frames, info, size = bo.synth_detections(n_frames=80, n_obj=24, seed=seed)
+    for f, d in enumerate(frames):
+        det = d if f % 7 else np.concatenate([d, np.ones((len(d), 1), np.float32)], 1)      # (N,6) rows every 7th frame
+        o = bo.byte_update(st, det, info, size)
+        r = trk.update(det, info, size)
+        assert [t.track_id for t in r] == [t.track_id for t in o], f
+        assert np.allclose(np.array([t.tlwh for t in r]).reshape(-1, 4), np.array([t.tlwh for t in o]).reshape(-1, 4), rtol=0, atol=1e-8)
+    assert nbt.id_count() == st.count
+
+
+def test_byte_native_edges():
+    nbt.clean_id()
+    trk = nbt.BYTETracker(types.SimpleNamespace(track_thresh=0.6, track_buffer=30, match_thresh=0.9, mot20=False))
+    assert trk.update(np.zeros((0, 5), np.float32), (1080, 1920), (800, 1440)) == []          # empty frame 1
+    one = np.array([[100, 100, 200, 300, 0.9]], np.float32)
+    assert trk.update(one, (1080, 1920), (800, 1440)) == []              # born after frame 1: unconfirmed until re-observed
+    out = trk.update(one, (1080, 1920), (800, 1440))
+    assert [t.track_id for t in out] == [1] and abs(out[0].tlwh[2] * out[0].tlwh[3] - (100 / 0.7407407) * (200 / 0.7407407)) < 60
+    with pytest.raises(ValueError):
+        trk.update(np.zeros((3, 4), np.float32), (1080, 1920), (800, 1440))

@@ -242,3 +242,365 @@ int uni_qd_match(uni_qd* t, const float* bboxes_in, const int64_t* labels_in, co
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// ByteTrack (byte_tracker.py, matching.py, kalman_filter.py).  float64 state like the reference (numpy default); the
+// detections arrive as float32 and the reference's float32 steps (score product, /scale, tlbr->tlwh, thresholds) are
+// reproduced in float32.  lap.lapjv(extend_cost, cost_limit) and cython_bbox.bbox_overlaps are third-party code absent
+// offline: implemented from their published semantics (exact assignment on the extended matrix; IoU with the +1 pixel
+// convention).
+// =====================================================================================================================
+#include <memory>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace {
+enum { ST_NEW = 0, ST_TRACKED = 1, ST_LOST = 2, ST_REMOVED = 3 };      // basetrack.py:5-9
+int64_t g_byte_count = 0;                                               // BaseTrack._count
+
+struct BTrack {                                                         // STrack (:13-140)
+    double tlwh0[4];
+    double mean[8], cov[64];
+    bool has_mean = false, is_activated = false;
+    float score = 0.f;
+    int tracklet_len = 0, state = ST_NEW, frame_id = 0, start_frame = 0;
+    int64_t track_id = 0;
+    void tlwh(double* r) const {
+        if (!has_mean) { for (int k = 0; k < 4; ++k) r[k] = tlwh0[k]; return; }
+        r[0] = mean[0]; r[1] = mean[1]; r[2] = mean[2]; r[3] = mean[3];
+        r[2] *= r[3];
+        r[0] -= r[2] / 2; r[1] -= r[3] / 2;
+    }
+    void tlbr(double* r) const { tlwh(r); r[2] += r[0]; r[3] += r[1]; }
+};
+typedef std::shared_ptr<BTrack> TP;
+
+void to_xyah(const double* tlwh, double* r) {                            // :117-125
+    r[0] = tlwh[0] + tlwh[2] / 2; r[1] = tlwh[1] + tlwh[3] / 2; r[2] = tlwh[2] / tlwh[3]; r[3] = tlwh[3];
+}
+
+// ---- Kalman filter: F = I + shift (dt = 1), H = [I4 0], weights 1/20 and 1/160 (kalman_filter.py:40-51)
+const double WP = 1.0 / 20, WV = 1.0 / 160;
+void kf_initiate(const double* m, double* mean, double* cov) {          // :53-79
+    for (int k = 0; k < 4; ++k) { mean[k] = m[k]; mean[4 + k] = 0; }
+    const double std[8] = {2 * WP * m[3], 2 * WP * m[3], 1e-2, 2 * WP * m[3], 10 * WV * m[3], 10 * WV * m[3], 1e-5, 10 * WV * m[3]};
+    for (int i = 0; i < 64; ++i) cov[i] = 0;
+    for (int k = 0; k < 8; ++k) cov[9 * k] = std[k] * std[k];
+}
+void kf_predict(double* mean, double* cov) {                            // multi_predict row (:110-142)
+    const double h = mean[3];
+    const double std[8] = {WP * h, WP * h, 1e-2, WP * h, WV * h, WV * h, 1e-5, WV * h};
+    for (int k = 0; k < 4; ++k) mean[k] += mean[4 + k];
+    double fc[64], out[64];                                             // F C, then (F C) F^T
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) fc[8 * i + j] = cov[8 * i + j] + (i < 4 ? cov[8 * (i + 4) + j] : 0.0);
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) out[8 * i + j] = fc[8 * i + j] + (j < 4 ? fc[8 * i + j + 4] : 0.0);
+    for (int i = 0; i < 64; ++i) cov[i] = out[i];
+    for (int k = 0; k < 8; ++k) cov[9 * k] += std[k] * std[k];
+}
+void kf_update(double* mean, double* cov, const double* z) {            // :143-168 (project :88-109)
+    const double h = mean[3];
+    const double std[4] = {WP * h, WP * h, 1e-1, WP * h};
+    double S[16], L[16] = {0};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) S[4 * i + j] = cov[8 * i + j] + (i == j ? std[i] * std[i] : 0.0);
+    for (int i = 0; i < 4; ++i)                                         // Cholesky S = L L^T
+        for (int j = 0; j <= i; ++j) {
+            double s = S[4 * i + j];
+            for (int k = 0; k < j; ++k) s -= L[4 * i + k] * L[4 * j + k];
+            L[4 * i + j] = i == j ? std::sqrt(s) : s / L[4 * j + j];
+        }
+    double K[32];                                                       // K (8x4): solve S K^T = (P H^T)^T row by row
+    for (int r = 0; r < 8; ++r) {
+        double y[4], x[4];
+        for (int i = 0; i < 4; ++i) {
+            double s = cov[8 * r + i];                                  // (P H^T)[r][i] = P[r][i]
+            for (int k = 0; k < i; ++k) s -= L[4 * i + k] * y[k];
+            y[i] = s / L[4 * i + i];
+        }
+        for (int i = 3; i >= 0; --i) {
+            double s = y[i];
+            for (int k = i + 1; k < 4; ++k) s -= L[4 * k + i] * x[k];
+            x[i] = s / L[4 * i + i];
+        }
+        for (int i = 0; i < 4; ++i) K[4 * r + i] = x[i];
+    }
+    double inn[4];
+    for (int i = 0; i < 4; ++i) inn[i] = z[i] - mean[i];
+    for (int r = 0; r < 8; ++r) {
+        double s = 0;
+        for (int i = 0; i < 4; ++i) s += inn[i] * K[4 * r + i];
+        mean[r] += s;
+    }
+    double KS[32];
+    for (int r = 0; r < 8; ++r)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int i = 0; i < 4; ++i) s += K[4 * r + i] * S[4 * i + j];
+            KS[4 * r + j] = s;
+        }
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+            double s = 0;
+            for (int j = 0; j < 4; ++j) s += KS[4 * r + j] * K[4 * c + j];
+            cov[8 * r + c] -= s;
+        }
+}
+
+// cython_bbox.bbox_overlaps element (+1 convention)
+double iou_p1(const double* a, const double* b) {
+    const double iw = std::min(a[2], b[2]) - std::max(a[0], b[0]) + 1;
+    if (iw <= 0) return 0;
+    const double ih = std::min(a[3], b[3]) - std::max(a[1], b[1]) + 1;
+    if (ih <= 0) return 0;
+    const double ua = (a[2] - a[0] + 1) * (a[3] - a[1] + 1) + (b[2] - b[0] + 1) * (b[3] - b[1] + 1) - iw * ih;
+    return iw * ih / ua;
+}
+std::vector<double> iou_distance(const std::vector<TP>& a, const std::vector<TP>& b) {     // matching.py:75-91
+    std::vector<double> d(a.size() * b.size());
+    std::vector<double> ab(4 * a.size()), bb(4 * b.size());
+    for (size_t i = 0; i < a.size(); ++i) a[i]->tlbr(&ab[4 * i]);
+    for (size_t j = 0; j < b.size(); ++j) b[j]->tlbr(&bb[4 * j]);
+    for (size_t i = 0; i < a.size(); ++i)
+        for (size_t j = 0; j < b.size(); ++j) d[i * b.size() + j] = 1 - iou_p1(&ab[4 * i], &bb[4 * j]);
+    return d;
+}
+void fuse_score(std::vector<double>& cost, size_t nr, const std::vector<TP>& dets) {       // matching.py:173-181
+    for (size_t i = 0; i < nr; ++i)
+        for (size_t j = 0; j < dets.size(); ++j) cost[i * dets.size() + j] = 1 - (1 - cost[i * dets.size() + j]) * (double)dets[j]->score;
+}
+
+// exact linear assignment (shortest augmenting paths with potentials, O(n^3)) on the square matrix c (n x n)
+void solve_lap(int n, const std::vector<double>& c, std::vector<int>& row_to_col) {
+    const double INF = 1e300;
+    std::vector<double> u(n + 1, 0), v(n + 1, 0), minv(n + 1);
+    std::vector<int> p(n + 1, 0), way(n + 1, 0);
+    std::vector<char> used(n + 1);
+    for (int i = 1; i <= n; ++i) {
+        p[0] = i;
+        int j0 = 0;
+        std::fill(minv.begin(), minv.end(), INF);
+        std::fill(used.begin(), used.end(), 0);
+        do {
+            used[j0] = 1;
+            const int i0 = p[j0];
+            double delta = INF;
+            int j1 = 0;
+            for (int j = 1; j <= n; ++j)
+                if (!used[j]) {
+                    const double cur = c[(size_t)(i0 - 1) * n + (j - 1)] - u[i0] - v[j];
+                    if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                    if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+                }
+            for (int j = 0; j <= n; ++j)
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; } else minv[j] -= delta;
+            j0 = j1;
+        } while (p[j0] != 0);
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+    }
+    row_to_col.assign(n, -1);
+    for (int j = 1; j <= n; ++j) row_to_col[p[j] - 1] = j - 1;
+}
+// matching.py:39-51 with lap.lapjv(cost, extend_cost=True, cost_limit=thresh)
+void linear_assignment(const std::vector<double>& cost, int nr, int nc, double thresh, std::vector<std::pair<int, int>>& matches,
+                       std::vector<int>& u_rows, std::vector<int>& u_cols) {
+    matches.clear(); u_rows.clear(); u_cols.clear();
+    if (nr == 0 || nc == 0) {
+        for (int i = 0; i < nr; ++i) u_rows.push_back(i);
+        for (int j = 0; j < nc; ++j) u_cols.push_back(j);
+        return;
+    }
+    const int n = nr + nc;
+    std::vector<double> ext((size_t)n * n, thresh / 2.0);
+    for (int i = nr; i < n; ++i)
+        for (int j = nc; j < n; ++j) ext[(size_t)i * n + j] = 0;
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < nc; ++j) ext[(size_t)i * n + j] = cost[(size_t)i * nc + j];
+    std::vector<int> r2c;
+    solve_lap(n, ext, r2c);
+    std::vector<char> col_used(nc, 0);
+    for (int i = 0; i < nr; ++i) {
+        if (r2c[i] < nc) { matches.emplace_back(i, r2c[i]); col_used[r2c[i]] = 1; } else u_rows.push_back(i);
+    }
+    for (int j = 0; j < nc; ++j)
+        if (!col_used[j]) u_cols.push_back(j);
+}
+
+std::vector<TP> joint_stracks(const std::vector<TP>& a, const std::vector<TP>& b) {        // :296-308
+    std::unordered_set<int64_t> seen;
+    std::vector<TP> res;
+    for (const TP& t : a) { seen.insert(t->track_id); res.push_back(t); }
+    for (const TP& t : b)
+        if (seen.insert(t->track_id).second) res.push_back(t);
+    return res;
+}
+}  // namespace
+
+struct uni_byte {
+    uni_byte_cfg cfg;
+    double det_thresh;
+    int max_time_lost;
+    int frame_id = 0;
+    std::vector<TP> tracked, lost;
+    std::unordered_set<int64_t> removed_ids;     // self.removed_stracks is only ever consulted by track_id (:281)
+};
+
+extern "C" {
+
+uni_byte* uni_byte_create(const uni_byte_cfg* cfg) {
+    if (!cfg) { set_err("uni_byte_create: NULL cfg"); return nullptr; }
+    uni_byte* t = new uni_byte();
+    t->cfg = *cfg;
+    t->det_thresh = (double)cfg->track_thresh + 0.1;                                        // :152
+    t->max_time_lost = (int)((cfg->frame_rate > 0 ? cfg->frame_rate : 30) / 30.0 * cfg->track_buffer);   // :153-154
+    return t;
+}
+void uni_byte_destroy(uni_byte* t) { delete t; }
+int64_t uni_byte_id_count(void) { return g_byte_count; }
+void uni_byte_clean_id(void) { g_byte_count = 0; }
+int uni_byte_lost(const uni_byte* t, int64_t* ids_out, int capacity) {
+    if (!t) return -1;
+    for (size_t i = 0; i < t->lost.size() && (int)i < capacity; ++i) ids_out[i] = t->lost[i]->track_id;
+    return (int)t->lost.size();
+}
+
+int uni_byte_update(uni_byte* t, const float* dets_in, int n, int ld, double img_h, double img_w, double size_h, double size_w,
+                    int cap, double* out_tlwh, float* out_score, int64_t* out_id, int* n_out) {
+    if (!t || !n_out || n < 0 || (n > 0 && (!dets_in || ld < 5)) || (cap > 0 && (!out_tlwh || !out_score || !out_id))) {
+        set_err("uni_byte_update: bad argument");
+        return -1;
+    }
+    t->frame_id += 1;
+    std::vector<TP> activated, refind, lost_new;
+    std::vector<int64_t> removed_new;
+    const float scale = (float)std::min(size_h / img_h, size_w / img_w);                   // :172-174 (float32 array / python float)
+    const float thr = t->cfg.track_thresh;
+    std::vector<TP> dets, dets2;
+    for (int i = 0; i < n; ++i) {
+        const float* r = dets_in + (size_t)i * ld;
+        const float sc = ld == 5 ? r[4] : r[4] * r[5];                                     // :165-171
+        const float x1 = r[0] / scale, y1 = r[1] / scale, x2 = r[2] / scale, y2 = r[3] / scale;
+        const bool hi = sc > thr, lo = sc > 0.1f && sc < thr;                              // :176-180
+        if (!hi && !lo) continue;
+        TP d = std::make_shared<BTrack>();
+        d->tlwh0[0] = x1; d->tlwh0[1] = y1; d->tlwh0[2] = (float)(x2 - x1); d->tlwh0[3] = (float)(y2 - y1);   // tlbr_to_tlwh in float32
+        d->score = sc;
+        (hi ? dets : dets2).push_back(d);
+    }
+    std::vector<TP> unconfirmed, tracked;                                                  // :196-201
+    for (const TP& tr : t->tracked) (tr->is_activated ? tracked : unconfirmed).push_back(tr);
+    std::vector<TP> pool = joint_stracks(tracked, t->lost);                                // :204
+    for (const TP& tr : pool) {                                                            // multi_predict (:33-45)
+        if (tr->state != ST_TRACKED) tr->mean[7] = 0;
+        kf_predict(tr->mean, tr->cov);
+    }
+    auto hit = [&](const TP& tr, const TP& det) {                                          // update (:75-91) / re_activate (:61-73)
+        double tl[4], z[4];
+        det->tlwh(tl);
+        to_xyah(tl, z);
+        kf_update(tr->mean, tr->cov, z);
+        if (tr->state == ST_TRACKED) { tr->tracklet_len += 1; activated.push_back(tr); }
+        else { tr->tracklet_len = 0; refind.push_back(tr); }
+        tr->frame_id = t->frame_id;
+        tr->state = ST_TRACKED;
+        tr->is_activated = true;
+        tr->score = det->score;
+    };
+    std::vector<std::pair<int, int>> matches;
+    std::vector<int> u_track, u_det, u_track2, u_det2, u_unc;
+    {   // first association (:207-224)
+        std::vector<double> d = iou_distance(pool, dets);
+        if (!t->cfg.mot20) fuse_score(d, pool.size(), dets);
+        linear_assignment(d, (int)pool.size(), (int)dets.size(), t->cfg.match_thresh, matches, u_track, u_det);
+        for (auto& m : matches) hit(pool[m.first], dets[m.second]);
+    }
+    std::vector<TP> r_tracked;                                                             // :234
+    for (int i : u_track)
+        if (pool[i]->state == ST_TRACKED) r_tracked.push_back(pool[i]);
+    {   // second association with the low-score detections (:226-252)
+        std::vector<double> d = iou_distance(r_tracked, dets2);
+        linear_assignment(d, (int)r_tracked.size(), (int)dets2.size(), 0.5, matches, u_track2, u_det2);
+        for (auto& m : matches) hit(r_tracked[m.first], dets2[m.second]);
+        for (int i : u_track2)
+            if (r_tracked[i]->state != ST_LOST) { r_tracked[i]->state = ST_LOST; lost_new.push_back(r_tracked[i]); }
+    }
+    std::vector<TP> rest;                                                                  // :255
+    for (int i : u_det) rest.push_back(dets[i]);
+    {   // unconfirmed tracks (:256-266)
+        std::vector<double> d = iou_distance(unconfirmed, rest);
+        if (!t->cfg.mot20) fuse_score(d, unconfirmed.size(), rest);
+        linear_assignment(d, (int)unconfirmed.size(), (int)rest.size(), 0.7, matches, u_unc, u_det);
+        for (auto& m : matches) hit(unconfirmed[m.first], rest[m.second]);
+        for (int i : u_unc) { unconfirmed[i]->state = ST_REMOVED; removed_new.push_back(unconfirmed[i]->track_id); }
+    }
+    for (int i : u_det) {                                                                  // new tracks (:268-274), activate (:47-59)
+        const TP& tr = rest[i];
+        if (tr->score < (float)t->det_thresh) continue;
+        tr->track_id = ++g_byte_count;
+        double z[4];
+        to_xyah(tr->tlwh0, z);
+        kf_initiate(z, tr->mean, tr->cov);
+        tr->has_mean = true;
+        tr->tracklet_len = 0;
+        tr->state = ST_TRACKED;
+        tr->is_activated = t->frame_id == 1;
+        tr->frame_id = tr->start_frame = t->frame_id;
+        activated.push_back(tr);
+    }
+    for (const TP& tr : t->lost)                                                           // :276-279
+        if (t->frame_id - tr->frame_id > t->max_time_lost) { tr->state = ST_REMOVED; removed_new.push_back(tr->track_id); }
+    // ---- state update (:283-291)
+    std::vector<TP> keep;
+    for (const TP& tr : t->tracked)
+        if (tr->state == ST_TRACKED) keep.push_back(tr);
+    t->tracked = joint_stracks(joint_stracks(keep, activated), refind);
+    auto sub_by_ids = [](const std::vector<TP>& a, const std::unordered_set<int64_t>& ids) {   // sub_stracks (:311-320): dict by id
+        std::vector<TP> res;
+        std::unordered_map<int64_t, size_t> pos;
+        for (const TP& x : a) {
+            auto it = pos.find(x->track_id);
+            if (it == pos.end()) { pos[x->track_id] = res.size(); res.push_back(x); } else res[it->second] = x;
+        }
+        std::vector<TP> out;
+        for (const TP& x : res)
+            if (!ids.count(x->track_id)) out.push_back(x);
+        return out;
+    };
+    std::unordered_set<int64_t> tracked_ids;
+    for (const TP& tr : t->tracked) tracked_ids.insert(tr->track_id);
+    t->lost = sub_by_ids(t->lost, tracked_ids);
+    for (const TP& tr : lost_new) t->lost.push_back(tr);
+    t->lost = sub_by_ids(t->lost, t->removed_ids);
+    for (int64_t id : removed_new) t->removed_ids.insert(id);
+    {   // remove_duplicate_stracks (:323-337)
+        std::vector<double> pd = iou_distance(t->tracked, t->lost);
+        std::vector<char> dupa(t->tracked.size(), 0), dupb(t->lost.size(), 0);
+        for (size_t p = 0; p < t->tracked.size(); ++p)
+            for (size_t q = 0; q < t->lost.size(); ++q)
+                if (pd[p * t->lost.size() + q] < 0.15) {
+                    const int tp = t->tracked[p]->frame_id - t->tracked[p]->start_frame;
+                    const int tq = t->lost[q]->frame_id - t->lost[q]->start_frame;
+                    if (tp > tq) dupb[q] = 1; else dupa[p] = 1;
+                }
+        std::vector<TP> ra, rb;
+        for (size_t p = 0; p < t->tracked.size(); ++p) if (!dupa[p]) ra.push_back(t->tracked[p]);
+        for (size_t q = 0; q < t->lost.size(); ++q) if (!dupb[q]) rb.push_back(t->lost[q]);
+        t->tracked.swap(ra);
+        t->lost.swap(rb);
+    }
+    int m = 0;
+    for (const TP& tr : t->tracked) {                                                      // :293
+        if (!tr->is_activated) continue;
+        if (m < cap) {
+            tr->tlwh(out_tlwh + 4 * m);
+            out_score[m] = tr->score;
+            out_id[m] = tr->track_id;
+        }
+        ++m;
+    }
+    *n_out = m < cap ? m : cap;
+    return 0;
+}
+
+}  // extern "C"

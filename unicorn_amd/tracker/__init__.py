@@ -1,2 +1,3 @@
 from .unicorn_sot import UnicornSOTTrack  # noqa: F401
 from .quasi_dense_embed_tracker import QuasiDenseEmbedTracker  # noqa: F401
+from .byte_tracker import BYTETracker  # noqa: F401
