@@ -26,6 +26,7 @@
  *                            condinst/mask_branch.py:77-99,158-162)
  *   uni_condinst_masks      DynamicMaskHead.__call__ + aligned_bilinear(d_rate)
  *                           (condinst/dynamic_mask_head.py:172-225; utils/boxes.py:138-146)
+ *   uni_letterbox           PreprocessorX.process / preproc (unicorn_sot.py:111-123, data/data_augment.py:194-214)
  *   uni_postprocess         postprocess + torchvision nms/batched_nms (utils/boxes.py:33-77)
  *   uni_prior_pyramid       F.interpolate(coarse, 1/2 | 1/4, bilinear) (unicorn_sot.py:103-105)
  *   uni_label_map_s8        get_label_map + F.interpolate(1/8) (unicorn_sot.py:52-53,128-139)
@@ -124,6 +125,13 @@ int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const 
 int uni_condinst_masks(const float* mask_feats, const float* up_masks, const float* params, int ldp,
                        const float* inst_loc, const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate,
                        float* out, void* workspace, size_t workspace_bytes, uni_stream_t stream);
+
+/* Input letterbox on the device (row 0 / N1): PreprocessorX.process (external/lib/test/tracker/unicorn_sot.py:111-123,
+ * swap_rb = 1) and preproc (unicorn/data/data_augment.py:194-214, swap_rb = 0).  img_hwc: (h, w, 3) uint8 DEVICE buffer;
+ * out_chw: (3, H, W) fp32 = cv2.resize(INTER_LINEAR, 8-bit fixed point) to (int(w r), int(h r)), r = min(H/h, W/w),
+ * top-left aligned, padded with 114.  *r_out (host, optional) receives r. */
+int uni_letterbox(const uint8_t* img_hwc, int h, int w, int swap_rb, int H, int W, float* out_chw, double* r_out,
+                  uni_stream_t stream);
 
 /* Detection post-processing of ONE image on the device (row N1): unicorn/utils/boxes.py:33-77 `postprocess`
  * (+ torchvision.ops.nms / batched_nms semantics).  pred: (A, ld >= 5+num_classes) decoded [cx,cy,w,h,obj,cls...] fp32,

@@ -415,3 +415,18 @@ def test_nms_wrappers(L):
     assert torch.equal(nms(boxes.cuda(), scores.cuda(), 0.5).cpu(), uo.nms(boxes, scores, 0.5))
     assert torch.equal(batched_nms(boxes.cuda(), scores.cuda(), cls.cuda(), 0.5).cpu(), uo.batched_nms(boxes, scores, cls, 0.5))
     assert nms(boxes[:0].cuda(), scores[:0].cuda(), 0.5).numel() == 0
+
+
+@pytest.mark.parametrize("shape,size,swap", [((1080, 1920), (800, 1280), True), ((480, 640), (800, 1280), True),
+                                             ((375, 1242), (800, 1280), False), ((97, 61), (320, 320), True),
+                                             ((800, 1280), (800, 1280), False), ((2160, 3840), (800, 1280), True)])
+def test_letterbox_device(L, shape, size, swap):
+    """uni_letterbox == the oracle's restatement of PreprocessorX.process / preproc (cv2 8-bit INTER_LINEAR), bit exact"""
+    import letterbox_oracle as lo
+    from unicorn_amd.ops import letterbox
+    g = np.random.default_rng(shape[0] + shape[1])
+    img = g.integers(0, 256, shape + (3,), dtype=np.uint8)
+    ref, r_ref = lo.letterbox(img, size, swap)
+    out, r = letterbox(img, size, swap_rb=swap)
+    assert r == r_ref and out.shape == (1, 3) + size
+    assert np.array_equal(out[0].cpu().numpy(), ref)

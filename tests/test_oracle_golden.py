@@ -102,3 +102,22 @@ def test_sot_step_matches_reference(exp, golden_dir):
             check(g, "det_mot", det[:64])
             emb = uo.sample_instance_embeddings(r["embed_cur"], det[:16, :4])
             check(g, "inst_embed", emb)
+
+
+def test_letterbox_oracle_known_answers():
+    """oracle/letterbox_oracle.py restates cv2.resize(INTER_LINEAR, uint8) (third-party, absent offline): properties every
+    correct implementation has -- identity, constants, the 3:1 / 1:3 pattern of an exact 2x upsample, the rounded 2x2 mean of
+    an exact 2x downsample -- plus the letterbox geometry of PreprocessorX.process (unicorn_sot.py:111-123)."""
+    import letterbox_oracle as lo
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(lo.cv2_resize_linear_u8(img, (53, 37)), img)
+    assert (lo.cv2_resize_linear_u8(np.full((20, 30, 3), 77, np.uint8), (91, 47)) == 77).all()
+    ramp = np.arange(0, 80, 8, dtype=np.uint8).reshape(1, 10, 1).repeat(3, 2)
+    assert lo.cv2_resize_linear_u8(ramp, (20, 1))[0, :, 0].tolist() == [0, 2, 6, 10, 14, 18, 22, 26, 30, 34, 38, 42, 46, 50, 54, 58,
+                                                                       62, 66, 70, 72]
+    blk = img[:36, :52].astype(np.int64).reshape(18, 2, 26, 2, 3).sum((1, 3))
+    assert np.array_equal(lo.cv2_resize_linear_u8(img[:36, :52], (26, 18)), ((blk + 2) >> 2).astype(np.uint8))
+    out, r = lo.letterbox(g.integers(0, 256, (1080, 1920, 3), dtype=np.uint8), (800, 1280), True)
+    assert out.shape == (3, 800, 1280) and r == 800 / 1200 or r == min(800 / 1080, 1280 / 1920)
+    assert (out[:, 720:, :] == 114).all() and out.dtype == np.float32

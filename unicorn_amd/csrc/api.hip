@@ -123,6 +123,10 @@ int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const 
     UNI_REQUIRE(embed_nhwc && (n == 0 || (boxes_xyxy && out)), "sample_embeddings: NULL argument");
     API(launch_sample_embed(embed_nhwc, H8, W8, C, boxes_xyxy, ld_boxes, n, stride, out, S(stream)));
 }
+int uni_letterbox(const uint8_t* img_hwc, int h, int w, int swap_rb, int H, int W, float* out_chw, double* r_out, uni_stream_t stream) {
+    UNI_REQUIRE(img_hwc && out_chw, "letterbox: NULL argument");
+    API(launch_letterbox(img_hwc, h, w, swap_rb, H, W, out_chw, r_out, S(stream)));
+}
 size_t uni_postprocess_workspace_bytes(int A) { return postprocess_workspace_bytes(A); }
 int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags, int max_det,
                     float* det_out, int32_t* keep_idx, int32_t* n_out, void* workspace, size_t workspace_bytes,

@@ -124,6 +124,7 @@ struct CondInstArgs {
 int launch_condinst(const CondInstArgs& a, hipStream_t s);
 int launch_label_map_s8(const float* box_xyxy, float* out, int H, int W, hipStream_t s);
 // post.hip: utils/boxes.py:33-77 on the device (corners in place, conf filter, (batched) NMS, sorted survivor rows)
+int launch_letterbox(const unsigned char* img, int h, int w, int swap_rb, int H, int W, float* out, double* r_out, hipStream_t s);
 size_t postprocess_workspace_bytes(int A);
 int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
                        int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t s);

@@ -9,6 +9,7 @@
 // (rank by counting, ties by anchor index), IoU is evaluated with the same fp32 operation order as the oracle with
 // contraction disabled, so kept indices are bit-identical to the CPU restatement.
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 constexpr int PT = 256;
@@ -212,5 +213,68 @@ int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_t
     const size_t lds = (size_t)words * 8;
     hipLaunchKernelGGL(post_sweep_kernel, dim3(1), dim3(1024), lds, s, pred, ld, w.order, w.cconf, w.cls, w.n_cand, words, w.mask,
                        max_det, det_out, keep_idx, n_out);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Input letterbox on the device (row 0 / N1): PreprocessorX.process (external/lib/test/tracker/unicorn_sot.py:111-123) and
+// preproc (unicorn/data/data_augment.py:194-214): uint8 HWC image -> resize by r = min(H/h, W/w) with cv2.resize
+// INTER_LINEAR semantics for 8-bit data (OpenCV resize.cpp: 11-bit fixed-point coefficients, int32 horizontal pass,
+// `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2` vertical pass) -> top-left aligned, pad 114, CHW fp32, optional
+// RGB<->BGR swap.  One thread per output pixel; integer arithmetic identical to oracle/letterbox_oracle.py.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Tap { int s0, s1, a0, a1; };
+__device__ __forceinline__ Tap lb_tap(int d, double scale, int n, bool clamp_weights) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);      // fx = (float)((dx+0.5)*scale_x - 0.5)
+    int s = (int)floorf(f);
+    f -= (float)s;
+    Tap t;
+    if (clamp_weights) {                                     // x: if (sx < 0) fx = 0, sx = 0; if (sx >= w-1) fx = 0, sx = w-1
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n - 1) { f = 0.f; s = n - 1; }
+        t.s0 = s;
+        t.s1 = min(s + 1, n - 1);
+    } else {                                                 // y: rows are clamped, weights are not
+        t.s0 = min(max(s, 0), n - 1);
+        t.s1 = min(max(s + 1, 0), n - 1);
+    }
+    t.a0 = __float2int_rn((1.f - f) * 2048.f);               // saturate_cast<short>: round half to even
+    t.a1 = __float2int_rn(f * 2048.f);
+    return t;
+}
+__global__ void letterbox_kernel(const unsigned char* __restrict__ img, int h, int w, int nh, int nw, int swap_rb, int H, int W,
+                                 float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float v[3] = {114.f, 114.f, 114.f};
+    if (x < nw && y < nh) {
+        const Tap tx = lb_tap(x, (double)w / nw, w, true), ty = lb_tap(y, (double)h / nh, h, false);
+        const unsigned char* r0 = img + ((size_t)ty.s0 * w) * 3;
+        const unsigned char* r1 = img + ((size_t)ty.s1 * w) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = swap_rb ? 2 - c : c;
+            const int h0 = r0[tx.s0 * 3 + cs] * tx.a0 + r0[tx.s1 * 3 + cs] * tx.a1;
+            const int h1 = r1[tx.s0 * 3 + cs] * tx.a0 + r1[tx.s1 * 3 + cs] * tx.a1;
+            int o = (((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            o = min(max(o, 0), 255);
+            v[c] = (float)o;
+        }
+    }
+    const size_t plane = (size_t)H * W;
+    out[(size_t)y * W + x] = v[0];
+    out[plane + (size_t)y * W + x] = v[1];
+    out[2 * plane + (size_t)y * W + x] = v[2];
+}
+}  // namespace
+
+int launch_letterbox(const unsigned char* img, int h, int w, int swap_rb, int H, int W, float* out, double* r_out, hipStream_t s) {
+    UNI_REQUIRE(h > 0 && w > 0 && H > 0 && W > 0, "letterbox: empty image %dx%d -> %dx%d", h, w, H, W);
+    const double r = std::min((double)H / h, (double)W / w);          // unicorn_sot.py:116
+    const int nh = (int)(h * r), nw = (int)(w * r);                    // int(height * r), int(width * r)
+    UNI_REQUIRE(nh >= 1 && nw >= 1 && nh <= H && nw <= W, "letterbox: degenerate resize %dx%d", nh, nw);
+    if (r_out) *r_out = r;
+    hipLaunchKernelGGL(letterbox_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, s, img, h, w, nh, nw, swap_rb, H, W, out);
     return 0;
 }

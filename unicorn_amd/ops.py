@@ -144,3 +144,24 @@ def postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnost
     if m == 0:
         return None, None
     return det[:m], keep[:m].long()
+
+
+def letterbox(image, input_size, swap_rb=True, device=None):
+    """PreprocessorX.process (unicorn_sot.py:111-123, swap_rb=True) / preproc (data_augment.py:194-214, swap_rb=False) on the
+    device: image (h, w, 3) uint8 (numpy array or cuda tensor) -> ((1, 3, H, W) float32 cuda tensor, r)."""
+    import ctypes as C
+    if not torch.is_tensor(image):
+        import numpy as np
+        image = torch.from_numpy(np.ascontiguousarray(image))
+    if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
+        raise UnicornHipError("letterbox: needs an (h, w, 3) uint8 image")
+    if not image.is_cuda:
+        image = image.to(device if device is not None else "cuda", non_blocking=True)
+    image = image.contiguous()
+    H, W = int(input_size[0]), int(input_size[1])
+    out = torch.empty((1, 3, H, W), device=image.device, dtype=torch.float32)
+    r = C.c_double(0.0)
+    with torch.cuda.device(image.device):
+        L.check(L.lib().uni_letterbox(L.ptr(image), image.shape[0], image.shape[1], int(bool(swap_rb)), H, W, L.ptr(out), C.byref(r),
+                                      L.stream_ptr()), "uni_letterbox")
+    return out, r.value

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ..ops import corr_softmax_pv, label_map_s8, prior_pyramid
+from ..ops import corr_softmax_pv, label_map_s8, letterbox, prior_pyramid
 from ..utils.boxes import postprocess
 
 
@@ -26,18 +26,10 @@ class UnicornSOTTrack:
         self.frame_id = 0
 
     def _prep(self, image):
-        """PreprocessorX.process (unicorn_sot.py:114-123): RGB->BGR, resize by r=min(H/h,W/w) (bilinear), pad 114."""
+        """PreprocessorX.process (unicorn_sot.py:111-123): RGB->BGR, cv2-style 8-bit bilinear resize by r=min(H/h,W/w), pad 114."""
         if torch.is_tensor(image) and image.dim() == 4:
             return image.to(self.device).float(), 1.0
-        arr = np.asarray(image)
-        h, w = arr.shape[:2]
-        H, W = self.input_size
-        r = min(H / h, W / w)
-        t = torch.from_numpy(np.ascontiguousarray(arr[:, :, ::-1])).to(self.device).float().permute(2, 0, 1)[None]
-        t = F.interpolate(t, size=(int(h * r), int(w * r)), mode="bilinear", align_corners=False)
-        out = torch.full((1, 3, H, W), 114.0, device=self.device)
-        out[:, :, :int(h * r), :int(w * r)] = t
-        return out, r
+        return letterbox(np.asarray(image), self.input_size, swap_rb=True, device=self.device)   # uni_letterbox (post.hip)
 
     def initialize(self, image, info):
         self.frame_id = 0
