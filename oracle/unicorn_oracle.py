@@ -553,3 +553,54 @@ def sot_pick_box(det: Optional[Tensor], H: int, W: int, r: float = 1.0, max_inst
     b[:, 2] -= b[:, 0]
     b[:, 3] -= b[:, 1]
     return [int(v) for v in b[0]]
+
+
+# --------------------------------------------------------------------------------------------
+# VOS driver step (external/lib/test/tracker/unicorn_vos.py)
+# --------------------------------------------------------------------------------------------
+def vos_init(P, cfg, img0: Tensor, boxes_xyxy: dict):
+    """unicorn_vos.py:43-68: backbone of the reference frame once, one stride-8 label map per object."""
+    _, d_pre = forward_backbone(P, cfg, img0)
+    H, W = img0.shape[-2:]
+    return {"dict_pre": d_pre, "lbs": {k: label_map_s8(b, H, W) for k, b in boxes_xyxy.items()}}
+
+
+def vos_step(P, cfg, state, img: Tensor, conf_thre: float = 0.001, nms_thre: float = 0.65, max_inst: int = 1):
+    """unicorn_vos.py:157-200 (get_det_results) + the per-object selection of :123-155: interaction / upsample / one
+    correlation per frame, then PER OBJECT: propagate its label map, head(mode="sot"), postprocess_inst, keep the best
+    instance.  Returns {obj_id: (det row (7,) | None, mask (H, W) probabilities at network resolution | None)}."""
+    fpn, d_cur = forward_backbone(P, cfg, img)
+    f_pre, f_cur = forward_interaction(P, state["dict_pre"], d_cur)
+    e_pre, e_cur = forward_upsample(P, f_pre), forward_upsample(P, f_cur)
+    dh, dw = d_cur["h"] * 2, d_cur["w"] * 2
+    H, W = img.shape[-2:]
+    out = {}
+    for obj_id, lbs in state["lbs"].items():
+        pred = correlation_propagate(e_pre.flatten(-2)[0], e_cur.flatten(-2)[0], lbs)
+        coarse = pred.view(1, -1, dh, dw).float()
+        head_out = head_mask_forward(P, cfg, fpn, prior_pyramid(coarse), "sot")
+        det, masks = postprocess_inst(cfg, head_out, 1, conf_thre, nms_thre)
+        if det is None:
+            out[obj_id] = (None, None)
+            continue
+        det = det.clone()
+        det[:, 0:4:2] = det[:, 0:4:2].clamp(min=0, max=W)
+        det[:, 1:4:2] = det[:, 1:4:2].clamp(min=0, max=H)
+        out[obj_id] = (det[0], masks[0, 0])
+    return out
+
+
+def vos_merge(prob: dict, H: int, W: int):
+    """unicorn_vos.py:105-121 soft aggregation: background = prod(1 - p_k), argmax over [background, objects] -> (H,W) uint8
+    object-id map.  prob: {obj_id (str/int): (H, W) float array}."""
+    import numpy as np
+    ids = [int(k) for k in prob]
+    merge = np.zeros((H, W, max(ids) + 1))
+    for k, p in prob.items():
+        merge[:, :, int(k)] = p
+    merge[:, :, 0] = np.prod(1 - np.stack(list(prob.values()), axis=-1), axis=-1)
+    lab = np.argmax(merge, axis=-1)
+    final = np.zeros((H, W), dtype=np.uint8)
+    for k in ids:
+        final[lab == k] = k
+    return final

@@ -318,3 +318,39 @@ def test_batched_frames_equal_single_frame_runs(precision):
         close(big[4][b:b + 1], singles[b][4], "prior")
         for j in (0, 2, 4, 5):     # outputs, dynamic params, mask feats, up masks
             close(big[5][j][b:b + 1], singles[b][5][j], "head[%d]" % j)
+
+
+def test_vos_tracker_object_batched_matches_oracle():
+    """UnicornVOSTrack (mirror of external/lib/test/tracker/unicorn_vos.py, row N3): ONE correlation + ONE batched head call
+    for all objects must reproduce the oracle's per-object loop (exact-fp32 mode): best box, mask, merged segmentation."""
+    from unicorn_amd.tracker import UnicornVOSTrack
+    m, cfg, P = build("unicorn_track_tiny_mask", "fp32")
+    H = W = 320
+    frames, box = synth.synth_clip(H, W, 2, seed=3)
+    boxes = {"1": box, "2": torch.tensor([40.0, 60.0, 150.0, 170.0]), "3": torch.tensor([180.0, 30.0, 300.0, 140.0])}
+    trk = UnicornVOSTrack(m, input_size=(H, W), d_rate=cfg.d_rate)
+    info = {"init_object_ids": list(boxes), "init_bbox": {k: [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])]
+                                                          for k, b in boxes.items()}}
+    trk.initialize(frames[0].cuda(), info)
+    res, r = trk.step(frames[1].cuda())
+    seg = trk.track(frames[1].cuda())["segmentation"]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        st = uo.vos_init(P, cfg, frames[0], boxes)
+        exp = uo.vos_step(P, cfg, st, frames[1])
+    prob = {}
+    for k in boxes:
+        d_o, m_o = exp[k]
+        d_h, m_h = res[k]
+        assert (d_o is None) == (d_h is None), k
+        if d_o is None:
+            prob[k] = np.zeros((H, W), np.float32)
+            continue
+        cx = lambda t: torch.stack([(t[0] + t[2]) / 2, (t[1] + t[3]) / 2, t[2] - t[0], t[3] - t[1]])[None]
+        assert float(box_iou_pairs(cx(d_h.cpu()), cx(d_o))[0]) > 0.999, k
+        assert abs(float(d_h[4] * d_h[5]) - float(d_o[4] * d_o[5])) < 1e-5
+        a, b = m_h.cpu() > 0.5, m_o > 0.5
+        assert float((a & b).sum()) / max(float((a | b).sum()), 1.0) > 0.995, k
+        assert float((m_h.cpu() - m_o).abs().max()) < 2e-3, k
+        prob[k] = m_o.numpy()
+    assert (seg == uo.vos_merge(prob, H, W)).mean() > 0.999

@@ -136,39 +136,64 @@ __global__ void post_iou_kernel(const float* __restrict__ sbox, const int* n_can
     mask[(size_t)i * words + blockIdx.x] = bits;
 }
 
-// greedy sweep (one block): walk the candidates in score order, OR the rows of the survivors into the removed set
+// greedy sweep (one block), 64 candidates per step: wave 0 resolves the chunk's internal order from the 64 diagonal words
+// (register loop with lane broadcasts, no barriers), every lane of it writes its own surviving row, then all threads OR the
+// rows of the chunk's survivors into the removed set of the later chunks.  2 barriers per 64 candidates instead of one per
+// candidate (conf 0.001 keeps ~all 21000 anchors as candidates: 21 ms -> < 1 ms).
 __global__ __launch_bounds__(1024) void post_sweep_kernel(const float* __restrict__ pred, int ld, const int* __restrict__ order,
                                                           const float* __restrict__ cconf, const int* __restrict__ cls,
                                                           const int* n_cand, int words, const unsigned long long* __restrict__ mask,
                                                           int max_det, float* __restrict__ det, int* __restrict__ keep_idx,
                                                           int* __restrict__ n_out) {
     extern __shared__ unsigned long long removed[];      // [words]
+    __shared__ unsigned long long keep_chunk;
     __shared__ int nk;
     const int n = *n_cand;
     const int nw = (n + 63) / 64;
+    const int lane = threadIdx.x & 63;
     for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
     if (threadIdx.x == 0) nk = 0;
-    __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;     // uniform
-        if (!dead) {
-            if (threadIdx.x == 0) {
-                const int k = nk;
+    for (int c = 0; c < nw; ++c) {
+        __syncthreads();                                  // removed[c] is final, nk is current
+        if (threadIdx.x < 64) {
+            unsigned long long rw = removed[c];
+            const int row = c * 64 + lane;
+            const unsigned long long diag = row < n ? mask[(size_t)row * words + c] : 0ull;     // bits j > lane of this chunk
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            unsigned long long km = 0ull;
+            const int lim = min(64, n - c * 64);
+            for (int i = 0; i < lim; ++i) {               // wave-uniform
+                const unsigned long long di = ((unsigned long long)__shfl(dhi, i, 64) << 32) | __shfl(dlo, i, 64);
+                if (!((rw >> i) & 1ull)) { km |= 1ull << i; rw |= di; }
+            }
+            const int base = nk;
+            if ((km >> lane) & 1ull) {
+                const int k = base + __popcll(km & ((1ull << lane) - 1ull));
                 if (k < max_det) {
-                    const int a = order[i];
+                    const int a = order[row];
                     const float* p = pred + (size_t)a * ld;
                     float* d = det + (size_t)k * 7;
                     d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3]; d[4] = p[4];
                     d[5] = cconf[a]; d[6] = (float)cls[a];
                     keep_idx[k] = a;
                 }
-                nk = k + 1;
             }
-            const unsigned long long* row = mask + (size_t)i * words;
-            for (int w = (i >> 6) + threadIdx.x; w < nw; w += blockDim.x) removed[w] |= row[w];
+            if (lane == 0) { keep_chunk = km; nk = base + __popcll(km); }
         }
         __syncthreads();
+        const unsigned long long km = keep_chunk;
+        for (int w = c + 1 + threadIdx.x; w < nw; w += blockDim.x) {
+            unsigned long long acc = removed[w];
+            unsigned long long bits = km;
+            while (bits) {
+                const int i = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                acc |= mask[(size_t)(c * 64 + i) * words + w];
+            }
+            removed[w] = acc;
+        }
     }
+    __syncthreads();
     if (threadIdx.x == 0) *n_out = nk < max_det ? nk : max_det;
 }
 }  // namespace

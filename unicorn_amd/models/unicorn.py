@@ -68,6 +68,9 @@ class UnicornHead:
         m = self._m
         m._require_ready()
         f = [nhwc(x) for x in xin]
+        Bp = mask_in[0].shape[0]
+        if f[0].shape[0] == 1 and Bp > 1:      # object-batched call (row N3): one image, Bp prior sets -> one head pass over Bp samples
+            f = [x.expand(Bp, -1, -1, -1).contiguous(memory_format=torch.channels_last) for x in f]
         B = f[0].shape[0]
         H, W = f[0].shape[2] * 8, f[0].shape[3] * 8
         pri = []
