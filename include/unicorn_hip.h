@@ -133,6 +133,16 @@ int uni_condinst_masks(const float* mask_feats, const float* up_masks, const flo
 int uni_letterbox(const uint8_t* img_hwc, int h, int w, int swap_rb, int H, int W, float* out_chw, double* r_out,
                   uni_stream_t stream);
 
+/* UnicornHead.decode_outputs (unicorn_head.py:467-482), in place: outputs (B, A, nch) raw [dx,dy,log w,log h,...] over the three
+ * levels (strides 8/16/32 of an HxW input, level-major like the head's concat) -> xy = (xy + grid) * stride, wh = exp(wh) * stride.
+ * (uni_head already returns decoded outputs; this entry serves callers that keep decode_in_inference=False.) */
+int uni_decode_outputs(float* outputs, int B, int H, int W, int nch, uni_stream_t stream);
+/* torchvision.ops.nms on caller boxes (unicorn/utils/boxes.py:58-64): boxes (n,4) xyxy, scores (n) -> keep_idx (n) int32 in
+ * descending-score order, *n_out (device int32).  workspace >= uni_nms_workspace_bytes(n). */
+size_t uni_nms_workspace_bytes(int n);
+int uni_nms(const float* boxes_xyxy, const float* scores, int n, float iou_thr, int32_t* keep_idx, int32_t* n_out, void* workspace,
+            size_t workspace_bytes, uni_stream_t stream);
+
 /* Detection post-processing of ONE image on the device (row N1): unicorn/utils/boxes.py:33-77 `postprocess`
  * (+ torchvision.ops.nms / batched_nms semantics).  pred: (A, ld >= 5+num_classes) decoded [cx,cy,w,h,obj,cls...] fp32,
  * converted to corners IN PLACE like the reference (:36-39).  Survivors, in descending obj*cls order:

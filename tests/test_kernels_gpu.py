@@ -430,3 +430,16 @@ def test_letterbox_device(L, shape, size, swap):
     out, r = letterbox(img, size, swap_rb=swap)
     assert r == r_ref and out.shape == (1, 3) + size
     assert np.array_equal(out[0].cpu().numpy(), ref)
+
+
+def test_decode_outputs_device(L):
+    """uni_decode_outputs == UnicornHead.decode_outputs (unicorn_head.py:467-482) as restated by the oracle, in place"""
+    g = torch.Generator().manual_seed(2)
+    H, W, nch, B = 320, 352, 6, 2
+    levels = [torch.randn(B, nch, H // s_, W // s_, generator=g) for s_ in (8, 16, 32)]
+    exp, _ = uo.decode_outputs([t.clone() for t in levels])
+    raw = torch.cat([t.flatten(2) for t in levels], 2).permute(0, 2, 1).contiguous()
+    d = raw.clone().cuda()
+    L.check(L.lib().uni_decode_outputs(L.ptr(d), B, H, W, nch, L.stream_ptr()), "decode")
+    torch.cuda.synchronize()
+    assert torch.allclose(d.cpu(), exp, rtol=1e-6, atol=1e-5)

@@ -39,6 +39,9 @@ PROTOS = {
     "uni_prior_pyramid": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
     "uni_label_map_s8": (c_i, [c_f, c_f, c_i, c_i, C.c_void_p]),
     "uni_letterbox": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(C.c_double), C.c_void_p]),
+    "uni_decode_outputs": (c_i, [c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    "uni_nms_workspace_bytes": (C.c_size_t, [c_i]),
+    "uni_nms": (c_i, [c_f, c_f, c_i, C.c_float, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uni_postprocess_workspace_bytes": (C.c_size_t, [c_i]),
     "uni_postprocess": (c_i, [c_f, c_i, c_i, c_i, C.c_float, C.c_float, c_i, c_i, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uni_sample_embeddings": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, C.c_float, c_f, C.c_void_p]),

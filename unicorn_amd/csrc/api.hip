@@ -127,6 +127,17 @@ int uni_letterbox(const uint8_t* img_hwc, int h, int w, int swap_rb, int H, int 
     UNI_REQUIRE(img_hwc && out_chw, "letterbox: NULL argument");
     API(launch_letterbox(img_hwc, h, w, swap_rb, H, W, out_chw, r_out, S(stream)));
 }
+size_t uni_nms_workspace_bytes(int n) { return nms_workspace_bytes(n); }
+int uni_nms(const float* boxes_xyxy, const float* scores, int n, float iou_thr, int32_t* keep_idx, int32_t* n_out, void* workspace,
+            size_t workspace_bytes, uni_stream_t stream) {
+    UNI_REQUIRE(n_out && (n == 0 || (boxes_xyxy && scores && keep_idx && workspace)), "nms: NULL argument");
+    API(launch_nms(boxes_xyxy, scores, n, iou_thr, keep_idx, n_out, workspace, workspace_bytes, S(stream)));
+}
+int uni_decode_outputs(float* outputs, int B, int H, int W, int nch, uni_stream_t stream) {
+    UNI_REQUIRE(outputs && B >= 1 && H % 32 == 0 && W % 32 == 0 && nch >= 5, "decode_outputs: bad argument");
+    const int w0 = W / 8, w1 = W / 16, w2 = W / 32;
+    API(launch_decode(outputs, outputs, (H / 8) * w0, w0, (H / 16) * w1, w1, (H / 32) * w2, w2, nch, S(stream), B));
+}
 size_t uni_postprocess_workspace_bytes(int A) { return postprocess_workspace_bytes(A); }
 int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags, int max_det,
                     float* det_out, int32_t* keep_idx, int32_t* n_out, void* workspace, size_t workspace_bytes,

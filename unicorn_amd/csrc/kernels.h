@@ -126,6 +126,9 @@ int launch_label_map_s8(const float* box_xyxy, float* out, int H, int W, hipStre
 // post.hip: utils/boxes.py:33-77 on the device (corners in place, conf filter, (batched) NMS, sorted survivor rows)
 int launch_letterbox(const unsigned char* img, int h, int w, int swap_rb, int H, int W, float* out, double* r_out, hipStream_t s);
 size_t postprocess_workspace_bytes(int A);
+size_t nms_workspace_bytes(int n);
+int launch_nms(const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep_idx, int32_t* n_out, void* ws,
+               size_t ws_bytes, hipStream_t s);
 int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
                        int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,

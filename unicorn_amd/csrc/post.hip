@@ -294,6 +294,38 @@ __global__ void letterbox_kernel(const unsigned char* __restrict__ img, int h, i
 }
 }  // namespace
 
+namespace {
+__global__ void nms_rows_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, float* __restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rows[6 * i + 0] = boxes[4 * i + 0]; rows[6 * i + 1] = boxes[4 * i + 1];
+    rows[6 * i + 2] = boxes[4 * i + 2]; rows[6 * i + 3] = boxes[4 * i + 3];
+    rows[6 * i + 4] = scores[i];
+    rows[6 * i + 5] = 1.f;
+}
+}  // namespace
+
+size_t nms_workspace_bytes(int n) { return postprocess_workspace_bytes(n) + (size_t)n * (6 + 7) * sizeof(float) + 256; }
+
+// torchvision.ops.nms(boxes xyxy, scores, iou_threshold) (unicorn/utils/boxes.py:58-64 call site): kept indices in
+// descending-score order.  Runs the post-processing kernels above on pre-cornered rows [x1,y1,x2,y2,score,1].
+int launch_nms(const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep_idx, int32_t* n_out, void* ws,
+               size_t ws_bytes, hipStream_t s) {
+    UNI_REQUIRE(n >= 0, "nms: n=%d", n);
+    UNI_REQUIRE(ws_bytes >= nms_workspace_bytes(n), "nms: workspace too small");
+    if (n == 0) {
+        UNI_CHECK_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), s));
+        return 0;
+    }
+    char* base = reinterpret_cast<char*>(ws);
+    const size_t off = (postprocess_workspace_bytes(n) + 255) & ~(size_t)255;
+    float* rows = reinterpret_cast<float*>(base + off);
+    float* det = rows + (size_t)n * 6;
+    hipLaunchKernelGGL(nms_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, boxes, scores, n, rows);
+    return launch_postprocess(rows, n, 6, 1, -INFINITY, iou_thr, /*class agnostic | corners*/ 3, n, det, keep_idx, n_out, base,
+                              postprocess_workspace_bytes(n), s);
+}
+
 int launch_letterbox(const unsigned char* img, int h, int w, int swap_rb, int H, int W, float* out, double* r_out, hipStream_t s) {
     UNI_REQUIRE(h > 0 && w > 0 && H > 0 && W > 0, "letterbox: empty image %dx%d -> %dx%d", h, w, H, W);
     const double r = std::min((double)H / h, (double)W / w);          // unicorn_sot.py:116

@@ -97,10 +97,11 @@ class UnicornHead:
         return self._run(xin, mask_in, mode)[0]
 
     def decode_outputs(self, outputs, dtype=None):
-        """unicorn_head.py:467-482 on raw (B,A,5+nc) outputs (in place)."""
-        grids, strides = self._m._grids(self.hw, outputs.device)
-        outputs[..., :2] = (outputs[..., :2] + grids) * strides
-        outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * strides
+        """unicorn_head.py:467-482 on raw (B,A,5+nc) outputs (in place, uni_decode_outputs)."""
+        if not (outputs.is_cuda and outputs.dtype == torch.float32 and outputs.is_contiguous()):
+            raise ValueError("decode_outputs: needs a contiguous float32 cuda tensor (B, A, 5+nc)")
+        H, W = self.hw[0][0] * 8, self.hw[0][1] * 8
+        L.check(L.lib().uni_decode_outputs(L.ptr(outputs), outputs.shape[0], H, W, outputs.shape[2], L.stream_ptr()), "uni_decode_outputs")
         return outputs
 
 

@@ -11,18 +11,26 @@ import torch
 from ..ops import condinst_masks, postprocess_image
 
 
+_nms_ws = {}
+
+
 def nms(boxes, scores, thr):
-    """torchvision.ops.nms on the device: kept indices in descending-score order."""
+    """torchvision.ops.nms on the device (uni_nms): kept indices in descending-score order."""
+    from .. import _lib as L
     n = boxes.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.long, device=boxes.device)
-    # rows [x1,y1,x2,y2, obj = score, cls_conf = 1]: class-agnostic pass without a confidence cut on pre-cornered boxes
-    pred = torch.empty((n, 6), device=boxes.device, dtype=torch.float32)
-    pred[:, :4] = boxes.float()
-    pred[:, 4] = scores.float()
-    pred[:, 5] = 1.0
-    det, keep = postprocess_image(pred, 1, float("-inf"), thr, class_agnostic=True, precornered=True)
-    return keep if keep is not None else torch.empty((0,), dtype=torch.long, device=boxes.device)
+    b, sc = boxes.float().contiguous(), scores.float().contiguous()
+    need = L.lib().uni_nms_workspace_bytes(n)
+    key = (b.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _nms_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=b.device, dtype=torch.uint8)
+        _nms_ws[key] = ws
+    keep = torch.empty((n,), device=b.device, dtype=torch.int32)
+    cnt = torch.zeros((1,), device=b.device, dtype=torch.int32)
+    L.check(L.lib().uni_nms(L.ptr(b), L.ptr(sc), n, float(thr), L.ptr(keep), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream_ptr()), "uni_nms")
+    return keep[:int(cnt.item())].long()
 
 
 def batched_nms(boxes, scores, idxs, thr):
