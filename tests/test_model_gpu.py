@@ -320,7 +320,8 @@ def test_batched_frames_equal_single_frame_runs(precision):
             close(big[5][j][b:b + 1], singles[b][5][j], "head[%d]" % j)
 
 
-def test_vos_tracker_object_batched_matches_oracle():
+@pytest.mark.parametrize("batched", [True, False])
+def test_vos_tracker_object_batched_matches_oracle(batched):
     """UnicornVOSTrack (mirror of external/lib/test/tracker/unicorn_vos.py, row N3): ONE correlation + ONE batched head call
     for all objects must reproduce the oracle's per-object loop (exact-fp32 mode): best box, mask, merged segmentation."""
     from unicorn_amd.tracker import UnicornVOSTrack
@@ -328,7 +329,7 @@ def test_vos_tracker_object_batched_matches_oracle():
     H = W = 320
     frames, box = synth.synth_clip(H, W, 2, seed=3)
     boxes = {"1": box, "2": torch.tensor([40.0, 60.0, 150.0, 170.0]), "3": torch.tensor([180.0, 30.0, 300.0, 140.0])}
-    trk = UnicornVOSTrack(m, input_size=(H, W), d_rate=cfg.d_rate)
+    trk = UnicornVOSTrack(m, input_size=(H, W), d_rate=cfg.d_rate, object_batched=batched)
     info = {"init_object_ids": list(boxes), "init_bbox": {k: [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])]
                                                           for k, b in boxes.items()}}
     trk.initialize(frames[0].cuda(), info)

@@ -21,6 +21,7 @@ struct PostWs {                 // layout of the caller-provided workspace
     float* cconf;               // [A]
     int* cls;                   // [A]
     int* order;                 // [A]  anchor index of the r-th best candidate
+    int* rank;                  // [A]  stable descending rank of every candidate
     float* sbox;                // [A][4] class-offset boxes in sorted order
     unsigned long long* mask;   // [A][ceil(A/64)] suppression bits (allocated for n_cand rows only when called)
 };
@@ -63,26 +64,34 @@ __global__ void post_prep_kernel(float* __restrict__ pred, int A, int ld, int nc
     }
 }
 
-// stable descending rank among the candidates: rank(a) = #{b : s_b > s_a or (s_b == s_a and b < a)}
-__global__ void post_rank_kernel(const float* __restrict__ score, int A, int* __restrict__ order) {
+// stable descending rank among the candidates: rank(a) = #{b : s_b > s_a or (s_b == s_a and b < a)}.  The A x A comparison
+// is split over blockIdx.y slices of the b range (partial counts, integer atomics: order independent), a second kernel scatters.
+constexpr int RANK_SLICES = 8;
+__global__ void post_rank_kernel(const float* __restrict__ score, int A, int* __restrict__ rank) {
     __shared__ float tile[PT];
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     const float sa = a < A ? score[a] : -INFINITY;
     const bool cand = sa > -INFINITY;
-    int rank = 0;
-    for (int b0 = 0; b0 < A; b0 += PT) {
+    const int per = ((A + RANK_SLICES - 1) / RANK_SLICES + PT - 1) / PT * PT;      // slice length, multiple of the tile
+    const int b_lo = blockIdx.y * per, b_hi = min(A, b_lo + per);
+    int cnt = 0;
+    for (int b0 = b_lo; b0 < b_hi; b0 += PT) {
         __syncthreads();
-        tile[threadIdx.x] = (b0 + threadIdx.x < A) ? score[b0 + threadIdx.x] : -INFINITY;
+        tile[threadIdx.x] = (b0 + threadIdx.x < b_hi) ? score[b0 + threadIdx.x] : -INFINITY;
         __syncthreads();
         if (cand) {
-            const int lim = min(PT, A - b0);
+            const int lim = min(PT, b_hi - b0);
             for (int j = 0; j < lim; ++j) {
                 const float sb = tile[j];
-                rank += (sb > sa) || (sb == sa && b0 + j < a);
+                cnt += (sb > sa) || (sb == sa && b0 + j < a);
             }
         }
     }
-    if (cand) order[rank] = a;
+    if (cand && cnt) atomicAdd(&rank[a], cnt);
+}
+__global__ void post_scatter_kernel(const float* __restrict__ score, const int* __restrict__ rank, int A, int* __restrict__ order) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < A && score[a] > -INFINITY) order[rank[a]] = a;
 }
 
 __global__ void post_sortbox_kernel(const float* __restrict__ pred, int ld, const int* __restrict__ order,
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(1024) void post_sweep_kernel(const float* __restric
 
 size_t postprocess_workspace_bytes(int A) {
     const size_t words = (size_t)(A + 63) / 64;
-    return 256 + (size_t)A * (4 + 4 + 4 + 4 + 16) + (size_t)A * words * 8 + 256;
+    return 256 + (size_t)A * (4 + 4 + 4 + 4 + 4 + 16) + (size_t)A * words * 8 + 256;
 }
 
 int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
@@ -222,6 +231,7 @@ int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_t
     w.cconf = reinterpret_cast<float*>(q); q += (size_t)A * 4;
     w.cls = reinterpret_cast<int*>(q); q += (size_t)A * 4;
     w.order = reinterpret_cast<int*>(q); q += (size_t)A * 4;
+    w.rank = reinterpret_cast<int*>(q); q += (size_t)A * 4;
     w.sbox = reinterpret_cast<float*>(q); q += (size_t)A * 16;
     q = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(q) + 7) & ~uintptr_t(7));
     w.mask = reinterpret_cast<unsigned long long*>(q);
@@ -230,7 +240,9 @@ int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_t
     const int nb = cdiv(A, PT);
     hipLaunchKernelGGL(post_prep_kernel, dim3(nb), dim3(PT), 0, s, pred, A, ld, num_classes, conf_thre, (flags >> 1) & 1, w.score, w.cconf, w.cls,
                        w.n_cand, w.maxc_key);
-    hipLaunchKernelGGL(post_rank_kernel, dim3(nb), dim3(PT), 0, s, w.score, A, w.order);
+    UNI_CHECK_HIP(hipMemsetAsync(w.rank, 0, (size_t)A * sizeof(int), s));
+    hipLaunchKernelGGL(post_rank_kernel, dim3(nb, RANK_SLICES), dim3(PT), 0, s, w.score, A, w.rank);
+    hipLaunchKernelGGL(post_scatter_kernel, dim3(nb), dim3(PT), 0, s, w.score, w.rank, A, w.order);
     hipLaunchKernelGGL(post_sortbox_kernel, dim3(nb), dim3(PT), 0, s, pred, ld, w.order, w.cls, w.n_cand, w.maxc_key,
                        flags & 1, w.sbox);
     // the grid covers the worst case (every anchor a candidate); tiles beyond n_cand return immediately
