@@ -672,6 +672,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
                 (!a.outF || (a.ldf % 4 == 0 && al16(a.outF))) && (!a.outB || (a.ldb % 8 == 0 && al16(a.outB))) &&
                 !((a.force_cfg / 1000) & 32);
     }
+    static const bool no44 = getenv("UNI_NO44") != nullptr, no_p44 = getenv("UNI_NO_P44") != nullptr;   // A/B switches (read once)
     const long b44 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     const long b22 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const long b21 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
@@ -680,14 +681,14 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     int cfg = a.force_cfg % 1000;
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
-        else if (util44 >= 0.74 && (b44 >= 1500 || (b44 >= 384 && a.K >= 512)) && !getenv("UNI_NO44")) cfg = 44;
+        else if (util44 >= 0.74 && (b44 >= 1500 || (b44 >= 384 && a.K >= 512)) && !no44) cfg = 44;
         else if (b22 >= 512) cfg = 22;
         else if (conv) cfg = b22 >= 400 ? 22 : (b12 >= 400 ? 12 : 11);
         else cfg = b21 >= 400 ? 21 : 11;
     }
 #define GO(WM, WN, TM, TN, BK) return conv ? launch_cfg<WM, WN, TM, TN, BK, true>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false>(a, s)
     // plain GEMMs that would take the 256x256 tile go to the persistent variant (gemm_p44.hip): -5..-20 % on the MLP shapes
-    if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_p44_supported(a) && !getenv("UNI_NO_P44")) cfg = 144;
+    if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_p44_supported(a) && !no_p44) cfg = 144;
     if (cfg == 144 && !gemm_p44_supported(a)) cfg = 44;
     if (cfg == 144) return launch_gemm_p44(a, s);
     if (cfg == 88 && !gemm_pipe_supported(a)) cfg = 44;
