@@ -209,10 +209,11 @@ def test_groupnorm_act(L, C_, G, act):
     assert (outF.cpu() - exp).abs().max() < 1e-4 * max(1.0, exp.abs().max().item())
 
 
+@pytest.mark.parametrize("W", [96, 100, 1280])     # W % 16 == 0: 4-pixel kernel, otherwise the 1-pixel fallback
 @pytest.mark.parametrize("C_", [96, 192])
-def test_stem(L, C_):
+def test_stem(L, C_, W):
     g = torch.Generator().manual_seed(C_)
-    H, W = 64, 96
+    H = 64
     img = torch.rand(1, 3, H, W, generator=g) * 255
     w = torch.randn(C_, 3, 4, 4, generator=g) / 48 ** 0.5
     b, ga, be = torch.randn(C_, generator=g) * 0.1, 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
