@@ -196,7 +196,8 @@ __global__ __launch_bounds__(64 * NWV) void corr_split_kernel(const float* __res
     for (int c = 0; c < 8; ++c) {
         const f32x4* src = reinterpret_cast<const f32x4*>(ecur + (size_t)qc * CD + 16 * c + 8 * fh);
         const f32x4 t0 = src[0], t1 = src[1];
-        const float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        constexpr float L2E = 1.4426950408889634f;         // scores come out in the log2 domain (exp2 needs no pre-multiply)
+        const float x[8] = {t0[0] * L2E, t0[1] * L2E, t0[2] * L2E, t0[3] * L2E, t1[0] * L2E, t1[1] * L2E, t1[2] * L2E, t1[3] * L2E};
         split3(x, qh[c], qm[c], ql[c]);
     }
     const int r_begin = split * rows_per_split;
@@ -264,17 +265,23 @@ __global__ __launch_bounds__(64 * NWV) void corr_split_kernel(const float* __res
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
-        // online softmax over this tile's 16 rows owned by the lane (same as corr_f32_kernel)
+        // online softmax over this tile's 16 rows owned by the lane, log2 domain; rows past the split end exist only in
+        // its last tile, so the mask selects are skipped on full tiles (wave-uniform branch)
         const int r0 = r_begin + t * TR;
         float sc[16], tmax = -INFINITY;
+        if (r0 + TR <= r_end) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc[r] = (r0 + rowof(r, fh) < r_end) ? acc[r] : -INFINITY;
-            tmax = fmaxf(tmax, sc[r]);
+            for (int r = 0; r < 16; ++r) { sc[r] = acc[r]; tmax = fmaxf(tmax, sc[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = (r0 + rowof(r, fh) < r_end) ? acc[r] : -INFINITY;
+                tmax = fmaxf(tmax, sc[r]);
+            }
         }
         const float mn = fmaxf(m, tmax);
         if (mn > -INFINITY) {
-            const float f = (m > -INFINITY) ? __expf(m - mn) : 0.f;
+            const float f = (m > -INFINITY) ? __builtin_amdgcn_exp2f(m - mn) : 0.f;
             l *= f;
 #pragma unroll
             for (int k = 0; k < KV; ++k) o[k] *= f;
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(64 * NWV) void corr_split_kernel(const float* __res
                 float pr[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pr[j] = __expf(sc[4 * g + j] - mn);
+                    pr[j] = __builtin_amdgcn_exp2f(sc[4 * g + j] - mn);
                     l += pr[j];
                 }
 #pragma unroll
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(64 * NWV) void corr_split_kernel(const float* __res
         if (t + 1 < ntiles) sstore(buf ^ 1);
         __syncthreads();
     }
+    m *= 0.6931471805599453f;                              // back to the natural-log domain of the merge (-inf stays -inf)
     {
         const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
         const float M = fmaxf(m, m2);
