@@ -355,3 +355,18 @@ def test_vos_tracker_object_batched_matches_oracle(batched):
         assert float((m_h.cpu() - m_o).abs().max()) < 2e-3, k
         prob[k] = m_o.numpy()
     assert (seg == uo.vos_merge(prob, H, W)).mean() > 0.999
+
+
+def test_load_state_dict_reports_missing_and_unexpected():
+    """nn.Module.load_state_dict contract used by tools/track.py:188 (`strict=False` -> (missing, unexpected))"""
+    from unicorn_amd.models import Unicorn
+    cfg = uo.CONFIGS["unicorn_track_tiny"]
+    P = dict(synth.synth_state_dict(cfg))
+    del P["head.beta_1"]
+    P["head.some_new_tensor"] = torch.zeros(3)
+    m = Unicorn("unicorn_track_tiny").cuda(0)
+    res = m.load_state_dict(P, strict=False)
+    assert list(res.missing_keys) == ["head.beta_1"] and list(res.unexpected_keys) == ["head.some_new_tensor"]
+    m2 = Unicorn("unicorn_track_tiny").cuda(0)
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict(P, strict=True)

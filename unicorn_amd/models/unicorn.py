@@ -219,10 +219,14 @@ class Unicorn:
         nm = C.c_int(0)
         L.check(lib.uni_ctx_finalize(self._ctx, C.byref(nm)), "uni_ctx_finalize")
         missing = [lib.uni_ctx_missing_name(self._ctx, i).decode() for i in range(nm.value)]
-        if strict and missing:
-            raise RuntimeError("Error(s) in loading state_dict: missing keys %s" % missing[:8])
+        from ..utils.checkpoint import state_spec      # names the reference model owns (buffers / foreign keys are "unexpected")
+        spec = state_spec(dict(dims=self.dims, depths=self.depths, num_classes=self.num_classes, mask=self.mask,
+                               n_layer_att=self.n_layer_att, embed_dim=self.embed_dim, up_rate=self.up_rate))
+        unexpected = [k for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype.is_floating_point and k not in spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict: missing keys %s, unexpected keys %s" % (missing[:8], unexpected[:8]))
         self._ready = True
-        return _IncompatibleKeys(missing, [])
+        return _IncompatibleKeys(missing, unexpected)
 
     def _require_ready(self):
         if self._ctx is None:
