@@ -121,3 +121,13 @@ def test_letterbox_oracle_known_answers():
     out, r = lo.letterbox(g.integers(0, 256, (1080, 1920, 3), dtype=np.uint8), (800, 1280), True)
     assert out.shape == (3, 800, 1280) and r == 800 / 1200 or r == min(800 / 1080, 1280 / 1920)
     assert (out[:, 720:, :] == 114).all() and out.dtype == np.float32
+
+
+@pytest.mark.parametrize("A,nc,agn", [(2100, 1, False), (5000, 8, False), (5000, 8, True), (333, 3, False)])
+def test_postprocess_oracle_matches_reference_golden(A, nc, agn):
+    """oracle.postprocess against the REAL reference function (unicorn/utils/boxes.py:33-77; tests/golden/make_golden_post.py) on
+    planted head outputs: same rows, same order (the torchvision NMS it calls is third-party, restated)."""
+    from planted import planted_pred
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess_planted.npz"))
+    det = uo.postprocess(planted_pred(A, nc, seed=A + nc), nc, 0.2, 0.45, class_agnostic=agn)[0]
+    assert np.array_equal(det.numpy(), gold["%d_%d_%d" % (A, nc, int(agn))])
