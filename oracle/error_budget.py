@@ -1,0 +1,178 @@
+"""Per-stage precision budget of the hot path (TEST INFRASTRUCTURE / analysis, CPU only).
+
+Question: which layers move box IoU when GEMM operands are narrower than fp32, and
+which operand format is the cheapest that keeps `box_iou_min_top500 >= 0.999` against the fp32 oracle?
+
+Method: the oracle's F.conv2d / F.linear are wrapped so that, per stage, BOTH operands are rounded to a
+chosen format before the (fp32-accumulated) contraction - exactly what an MFMA on split operands computes:
+  bf16     8-bit mantissa                     1 MFMA per product
+  f16      11-bit mantissa                    1 MFMA
+  bf16x2   hi + lo bf16 pieces (16 bits)      3 MFMAs (hi*hi, hi*lo, lo*hi)
+  f16x2    hi + lo f16 pieces (22 bits)       3 MFMAs
+  bf16x3   3 bf16 pieces (24 bits)            6 MFMAs
+Depthwise convs (groups > 1) are VALU fp32 in the HIP path and stay exact here.
+
+    python oracle/error_budget.py [--model unicorn_track_tiny] [--size 320 320]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import torch
+import torch.nn.functional as RF
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth  # noqa: E402
+import unicorn_oracle as uo  # noqa: E402
+
+
+def q_bf16(x):
+    return x.bfloat16().float()
+
+
+def q_f16(x):
+    return x.half().float()
+
+
+def q_bf16x2(x):
+    hi = x.bfloat16().float()
+    return hi + (x - hi).bfloat16().float()
+
+
+def q_bf16x3(x):
+    hi = x.bfloat16().float()
+    r = x - hi
+    mid = r.bfloat16().float()
+    return hi + mid + (r - mid).bfloat16().float()
+
+
+def q_f16x2(x):
+    hi = x.half().float()
+    return hi + (x - hi).half().float()
+
+
+QUANT = {"fp32": lambda x: x, "bf16": q_bf16, "f16": q_f16, "bf16x2": q_bf16x2, "f16x2": q_f16x2, "bf16x3": q_bf16x3}
+STAGES = ("backbone", "fpn", "interaction", "upsample", "head")
+
+
+class Policy:
+    def __init__(self, default="fp32", **per_stage):
+        self.fmt = {s: per_stage.get(s, default) for s in STAGES}
+        self.stage = "backbone"
+
+    def q(self, x):
+        return QUANT[self.fmt[self.stage]](x)
+
+
+POLICY = Policy()
+
+
+def _conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+    if groups == 1:
+        x, w = POLICY.q(x), POLICY.q(w)
+    return RF.conv2d(x, w, b, stride, padding, dilation, groups)
+
+
+def _linear(x, w, b=None):
+    return RF.linear(POLICY.q(x), POLICY.q(w), b)
+
+
+class _FProxy(types.ModuleType):
+    def __getattr__(self, k):
+        return getattr(RF, k)
+
+
+def install():
+    fp = _FProxy("F_quant")
+    fp.conv2d = _conv2d
+    fp.linear = _linear
+    uo.F = fp
+    # stage tags
+    for name, stage in (("convnext_features", "backbone"), ("pafpn", "fpn"), ("forward_interaction", "interaction"),
+                        ("forward_upsample", "upsample"), ("_head_trunk", "head"), ("mask_branch", "head")):
+        orig = getattr(uo, name)
+
+        def wrap(*a, _o=orig, _s=stage, **k):
+            prev, POLICY.stage = POLICY.stage, _s
+            try:
+                return _o(*a, **k)
+            finally:
+                POLICY.stage = prev
+        setattr(uo, name, wrap)
+
+
+def box_iou_pairs(a, b):
+    ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+    bx1, by1, bx2, by2 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    iw = (torch.min(ax2, bx2) - torch.max(ax1, bx1)).clamp(min=0)
+    ih = (torch.min(ay2, by2) - torch.max(ay1, by1)).clamp(min=0)
+    inter = iw * ih
+    return inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
+
+
+def run(P, cfg, frames, box, policy):
+    global POLICY
+    POLICY = policy
+    with torch.no_grad():
+        st = uo.sot_init(P, cfg, frames[0], box)
+        return uo.sot_step(P, cfg, st, frames[1])
+
+
+def metrics(o, ref, cfg):
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    ho = ref["head"][0] if cfg.mask else ref["head"]
+    hh = o["head"][0] if cfg.mask else o["head"]
+    score = ho[0, :, 4] * ho[0, :, 5]
+    top = torch.argsort(score, descending=True)[:500]
+    iou = box_iou_pairs(hh[0, top, :4], ho[0, top, :4])
+    ea, eb = o["embed_cur"].flatten(2)[0].double(), ref["embed_cur"].flatten(2)[0].double()
+    cos = (ea * eb).sum(0) / (ea.norm(dim=0) * eb.norm(dim=0))
+    m = {"seq_feat": rel(o["seq"]["feat"], ref["seq"]["feat"]), "fpn0": rel(o["fpn"][0], ref["fpn"][0]),
+         "fpn2": rel(o["fpn"][2], ref["fpn"][2]), "embed": rel(o["embed_cur"], ref["embed_cur"]),
+         "embed_cos_min": float(cos.min()), "prior_maxabs": float((o["coarse"] - ref["coarse"]).abs().max()),
+         "iou_min": float(iou.min()), "iou_mean": float(iou.mean()),
+         "score_rel": float(((hh[0, top, 4] * hh[0, top, 5] - score[top]).abs() / score[top]).max())}
+    if cfg.mask:
+        m["dyn"] = rel(o["head"][2], ref["head"][2])
+        m["mask_feats"] = rel(o["head"][4], ref["head"][4])
+    return m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="unicorn_track_tiny")
+    ap.add_argument("--size", type=int, nargs=2, default=[320, 320])
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--quick", action="store_true", help="uniform policies only")
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    install()
+    cfg = uo.CONFIGS[args.model]
+    P = synth.synth_state_dict(cfg)
+    H, W = args.size
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    ref = run(P, cfg, frames, box, Policy("fp32"))
+    rows = {}
+
+    def go(tag, pol):
+        rows[tag] = metrics(run(P, cfg, frames, box, pol), ref, cfg)
+        print(tag, json.dumps(rows[tag]), flush=True)
+
+    for f in ("bf16", "f16", "bf16x2", "f16x2", "bf16x3"):
+        go("all=" + f, Policy(f))
+    if not args.quick:
+        for s in STAGES:                                      # one stage narrow, rest exact: who moves IoU?
+            go("only_%s=bf16" % s, Policy("fp32", **{s: "bf16"}))
+        for s in STAGES:
+            go("only_%s=f16" % s, Policy("fp32", **{s: "f16"}))
+        go("bf16_backbone+bf16x2_rest", Policy("bf16x2", backbone="bf16"))
+        go("bf16x2_all_but_head_f16x2", Policy("bf16x2", head="f16x2"))
+    if args.out:
+        json.dump({"model": args.model, "size": [H, W], "rows": rows}, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
