@@ -162,6 +162,15 @@ int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, i
                   int KW, int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF,
                   int ldf, uint16_t* outB, int ldb, double* gn_stats, int cpg, int force_cfg, uni_stream_t stream);
 int uni_cast_bf16(const float* x, int ldx, uint16_t* out, int ldo, int M, int C, uni_stream_t stream);
+/* The same three for the "f16x2" operand format (precision 2: every value split into hi + lo f16 halves, per 8 channels a
+ * 32-byte group [8 x hi][8 x lo]; fp32-equivalent contraction as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16).
+ * Buffers are 4 bytes per element.  uni_pack_weight_h2 returns the power-of-two scale the packed tensor carries in
+ * *wscale_out (pass it to uni_gemm_h2, which multiplies the accumulator by it). */
+int uni_pack_weight_h2(const float* w_oihw_host, int N, int Cin, int KH, int KW, void* out_host, float* wscale_out);
+int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int M, int N, int Hin, int Win, int Cin, int KH,
+                int KW, int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF,
+                int ldf, void* outB, int ldb, double* gn_stats, int cpg, int force_cfg, uni_stream_t stream);
+int uni_cast_h2(const float* x, int ldx, void* out, int ldo, int M, int C, uni_stream_t stream);
 int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, float* outF,
                   uint16_t* outB, uni_stream_t stream);
 int uni_dwconv7_ln(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta,

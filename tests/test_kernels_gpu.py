@@ -423,3 +423,130 @@ def test_decode_outputs_device(L):
     L.check(L.lib().uni_decode_outputs(L.ptr(d), B, H, W, nch, L.stream_ptr()), "decode")
     torch.cuda.synchronize()
     assert torch.allclose(d.cpu(), exp, rtol=1e-6, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# "f16x2" operand format (precision 2): split-f16 buffers, fp32-equivalent GEMM (gemm_h2.hip)
+# ------------------------------------------------------------------------------------------------
+def h2_decode(buf, M, C):
+    """(M, C) FMT_H2 device buffer (int32 storage, 4 B per element) -> (hi + lo) fp32, and the two halves"""
+    h = buf.view(torch.float16).reshape(M, C // 8, 2, 8).float()
+    return (h[:, :, 0] + h[:, :, 1]).reshape(M, C), h[:, :, 0].reshape(M, C), h[:, :, 1].reshape(M, C)
+
+
+def cast_h2(L, x):
+    M, C_ = x.shape
+    out = torch.zeros((M, C_), device="cuda", dtype=torch.int32)
+    L.check(L.lib().uni_cast_h2(L.ptr(x), C_, L.ptr(out), C_, M, C_, L.stream_ptr()), "cast_h2")
+    return out
+
+
+def pack_weight_h2(L, w):
+    N, Cin, KH, KW = w.shape
+    K = Cin * KH * KW
+    Npad, Kpad = (N + 255) // 256 * 256, (K + 63) // 64 * 64
+    out = np.zeros((Npad, Kpad), dtype=np.uint32)
+    wc = np.ascontiguousarray(w.float().numpy())
+    sc = C.c_float(0)
+    L.check(L.lib().uni_pack_weight_h2(wc.ctypes.data_as(C.c_void_p), N, Cin, KH, KW, out.ctypes.data_as(C.c_void_p), C.byref(sc)), "pack_h2")
+    return torch.from_numpy(out.view(np.int32)).cuda(), sc.value
+
+
+def test_h2_cast_and_pack_formats(L):
+    """hi = f16(x), lo = f16(x - hi): 22 significand bits; tiny values keep an absolute error <= 2^-25 (f16 subnormals are
+    kept, not flushed); |x| up to 2 x 65504 stays finite.  The host packer applies a power-of-two scale and the same split."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(257, 64, generator=g)
+    x[0, :8] = torch.tensor([0.0, 1e-7, -3e-6, 65504.0, 1e5, -1.2e5, 6.1e-5, 1.0])   # beyond 65504 the lo half only extends the RANGE
+    x[1] *= 1e-3
+    x[2] *= 300.0
+    dec, hi, lo = h2_decode(cast_h2(L, x.cuda()), 257, 64)
+    dec, hi = dec.cpu(), hi.cpu()
+    assert torch.isfinite(dec).all()
+    assert torch.equal(hi[1:], x[1:].half().float())
+    err = (dec - x).abs()
+    assert (err <= x.abs() * 2.0 ** -21 + 2.0 ** -25).all(), err.max()
+    w = torch.randn(40, 16, 3, 3, generator=g) * 0.02
+    Wp, wscale = pack_weight_h2(L, w)
+    K = 16 * 9
+    wd, _, _ = h2_decode(Wp[:40], 40, Wp.shape[1])
+    wd = wd[:, :K].cpu() * wscale
+    ref = w.permute(0, 2, 3, 1).reshape(40, K)            # (ky, kx, c) order
+    assert np.log2(1.0 / wscale) == round(np.log2(1.0 / wscale))
+    assert (wd - ref).abs().max() <= ref.abs().max() * 2.0 ** -21
+
+
+@pytest.mark.parametrize("cfg", [0, 44, 22, 12, 21, 11])
+@pytest.mark.parametrize("case", [
+    # (Hin, Win, Cin, N, KH, stride, pad, act, bias, res, stats_G)
+    (20, 24, 96, 384, 1, 1, 0, 2, True, False, 0),        # pwconv1 + GELU, K = 96 (3 steps of 32)
+    (20, 24, 384, 96, 1, 1, 0, 0, True, True, 0),         # pwconv2 + residual
+    (25, 40, 256, 256, 3, 1, 1, 0, False, False, 16),     # head 3x3 + GN stats, ragged M
+    (26, 34, 192, 192, 3, 2, 1, 0, False, False, 16),     # 3x3 stride 2
+    (20, 20, 96, 192, 2, 2, 0, 0, True, False, 0),        # downsample 2x2/s2
+    (10, 10, 48, 48, 3, 1, 1, 0, False, False, 16),       # cpg = 3
+    (13, 17, 256, 5, 1, 1, 0, 4, True, False, 0),         # reg/obj preds N = 5 (fp32 out only)
+    (13, 17, 256, 169, 3, 1, 1, 0, True, False, 0),       # controller N = 169
+    (16, 16, 64, 256, 3, 1, 1, 1, True, False, 0),        # upsample_layer.1 + ReLU
+    (37, 29, 136, 264, 1, 1, 0, 3, True, False, 0),       # K tail (136 = 4 steps + 8), N = 256 + 8, SiLU
+])
+def test_gemm_h2(L, cfg, case):
+    """fp32-equivalent: compared with an fp64 contraction of the UNROUNDED fp32 operands."""
+    Hin, Win, Cin, N, k, stride, pad, act, use_bias, use_res, G = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(1, Cin, Hin, Win, generator=g) * 3.0
+    w = torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1 if use_bias else None
+    ref = F.conv2d(x.double(), w.double(), bias.double() if use_bias else None, stride=stride, padding=pad)
+    mag = F.conv2d(x.abs().double(), w.abs().double(), None, stride=stride, padding=pad)       # sum |a||w|: error scale
+    Hout, Wout = ref.shape[2:]
+    M = Hout * Wout
+    raw = ref.permute(0, 2, 3, 1).reshape(M, N)
+    mag = mag.permute(0, 2, 3, 1).reshape(M, N)
+    res = torch.randn(M, N, generator=g) if use_res else None
+    exp = ACTS[act](raw) + (res.double() if use_res else 0)
+    A = cast_h2(L, x.permute(0, 2, 3, 1).reshape(Hin * Win, Cin).contiguous().cuda())
+    Wp, wscale = pack_weight_h2(L, w)
+    outF = torch.full((M, N), float("nan"), device="cuda")
+    want_b = N % 8 == 0
+    outB = torch.zeros((M, N), device="cuda", dtype=torch.int32) if want_b else None
+    stats = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
+    bias_d = dev(bias) if use_bias else None
+    res_d = dev(res) if use_res else None
+    L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), wscale, M, N, Hin, Win, Cin, k, k, stride, pad,
+                                L.ptr(bias_d), act, L.ptr(res_d), N, L.ptr(outF), N, L.ptr(outB), N,
+                                L.ptr(stats), (N // G) if G else 0, cfg, L.stream_ptr()), "gemm_h2")
+    torch.cuda.synchronize()
+    got = outF.cpu().double()
+    assert torch.isfinite(got).all()
+    tol = mag * 2.0 ** -20 + 1e-6                     # operand split 2^-22 each side + fp32 accumulation; act slope <= ~1.1
+    assert ((got - exp).abs() <= tol * 1.2).all(), ((got - exp).abs() / tol).max()
+    if want_b:
+        dec, _, _ = h2_decode(outB, M, N)
+        assert ((dec.cpu().double() - exp).abs() <= tol * 1.2 + exp.abs() * 2.0 ** -21).all()
+    if G:
+        cpg = N // G
+        grp = raw.reshape(M, G, cpg)
+        s_ref = torch.stack([grp.sum((0, 2)), (grp ** 2).sum((0, 2))], 1)
+        s_got = stats.cpu()[:2 * G].reshape(G, 2)
+        assert torch.allclose(s_got, s_ref, rtol=2e-5, atol=2e-2), (s_got - s_ref).abs().max()    # sums of ~1e5 |terms| that nearly cancel
+
+
+def test_gemm_h2_large_and_subnormal_lo(L):
+    """256x256-tile path on a pwconv-sized problem + operands whose lo halves are f16 SUBNORMALS (|x| ~ 1e-2): the MFMA
+    must not flush them (error would jump from ~2^-22 to ~2^-12 relative)."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 30001, 768, 192
+    x = (torch.randn(M, K, generator=g) * 1e-2).cuda()
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    exp = x.double() @ w.double().cuda().t()
+    mag = x.abs().double() @ w.abs().double().cuda().t()
+    A = cast_h2(L, x)
+    Wp, wscale = pack_weight_h2(L, w.reshape(N, K, 1, 1))
+    for cfg in (0, 44, 22):
+        outF = torch.full((M, N), float("nan"), device="cuda")
+        L.check(L.lib().uni_gemm_h2(L.ptr(A), K, L.ptr(Wp), wscale, M, N, M, 1, K, 1, 1, 1, 0, None, 0, None, N,
+                                    L.ptr(outF), N, None, N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
+        torch.cuda.synchronize()
+        r = ((outF.double() - exp).abs() / (mag * 2.0 ** -20 + 1e-12)).max().item()
+        assert r < 1.5, (cfg, r)

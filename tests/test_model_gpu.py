@@ -90,7 +90,10 @@ def hip_sot_step(m, cfg, frames, box):
                 pri=pri, head=head)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+EXACT = ("fp32", "f16x2")      # precision modes that must meet the north_star bar
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
 @pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask"])
 def test_tiny_320_vs_reference_golden(exp, precision, golden_dir):
     """BASELINE.json configs[0] shapes; expected values come from the real reference (tests/golden/make_golden.py)."""
@@ -126,11 +129,11 @@ def test_tiny_320_vs_reference_golden(exp, precision, golden_dir):
     METRICS["golden_%s_%s" % (exp, precision)] = met
     _dump()
     assert met["seq_pos"] < 1e-5
-    feat_tol, prior_tol = (1e-4, 1e-4) if precision == "fp32" else (5e-2, 2e-2)
+    feat_tol, prior_tol = (1e-4, 1e-4) if precision in EXACT else (5e-2, 2e-2)
     for k in ("fpn0", "fpn1", "fpn2", "seq_feat", "feat_pre", "feat_cur", "embed_pre", "embed_cur"):
         assert met[k] < feat_tol, (k, met[k])
     assert met["coarse_maxabs"] < prior_tol
-    if precision == "fp32":
+    if precision in EXACT:
         assert met["box_iou_min_top200"] > 0.999, met
         assert met["score_relerr_top200"] < 1e-3
         if cfg.mask:
@@ -203,13 +206,13 @@ def _vs_oracle(exp, H, W, tag, precision="bf16"):
 
 
 def _assert_bar(met, precision):
-    feat_tol, prior_tol = (1e-4, 1e-4) if precision == "fp32" else (5e-2, 2e-2)
+    feat_tol, prior_tol = (1e-4, 1e-4) if precision in EXACT else (5e-2, 2e-2)
     for k in ("fpn0", "fpn1", "fpn2", "seq_feat", "feat_cur"):
         assert met[k] < feat_tol, (k, met[k])
     assert met["embed_cur_cos_min"] > 1 - 1e-4 and met["embed_pre_cos_min"] > 1 - 1e-4, met     # north_star: cosine within 1e-4
     assert met["corr_isolated_maxabs"] < 2e-5, met
     assert met["coarse_maxabs"] < prior_tol, met
-    if precision == "fp32":                                                                  # north_star: IoU >= 0.999
+    if precision in EXACT:                                                                   # north_star: IoU >= 0.999
         assert met["box_iou_min_top500"] > 0.999, met
         if "sot_box_iou" in met:
             assert met["sot_box_iou"] > 0.999, met
@@ -219,13 +222,13 @@ def _assert_bar(met, precision):
         assert met["box_iou_mean_top500"] > 0.75, met
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
 def test_tiny_sot_800x1280_vs_oracle(precision):
     """BASELINE.json configs[1]: unicorn_track_tiny SOT 800x1280 (bf16 backbone + fp32 correlation; and the exact mode)."""
     _assert_bar(_vs_oracle("unicorn_track_tiny", 800, 1280, "tiny_sot_800x1280_" + precision, precision), precision)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
 def test_tiny_mask_ragged_size_vs_oracle(precision):
     """VOS-style head (CondInst) at a non-square size that is ragged for every tile/strip/split: 352x608."""
     _assert_bar(_vs_oracle("unicorn_track_tiny_mask", 352, 608, "tiny_mask_352x608_" + precision, precision), precision)
@@ -275,7 +278,7 @@ def test_sot_tracker_and_postprocess_match_oracle_decision():
         assert all(abs(x - y) <= 1 for x, y in zip(a, b)), (got, exp)     # int truncation may flip by 1 px
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
 def test_batched_frames_equal_single_frame_runs(precision):
     """Every stage takes a batch of frames (M = B*H*W rows per kernel): B = 3 must reproduce three B = 1 runs
     (per-sample GroupNorm statistics, conv halos and the head's row remap must not leak across samples).
@@ -304,7 +307,7 @@ def test_batched_frames_equal_single_frame_runs(precision):
     torch.cuda.synchronize()
     # bf16: the fp64 GN-statistics atomics arrive in a different order -> a different last bit of rstd can flip a bf16
     # rounding, which the random-weight head then amplifies; the exact-fp32 mode pins the batching logic itself
-    tol = 2e-5 if precision == "fp32" else 1e-1
+    tol = 2e-5 if precision in EXACT else 1e-1
     def close(a, b, what):
         a, b = a.float().cpu(), b.float().cpu()
         err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())

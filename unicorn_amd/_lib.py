@@ -50,6 +50,10 @@ PROTOS = {
     "uni_gemm_bf16": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i,
                             c_f, c_i, c_i, C.c_void_p]),
     "uni_cast_bf16": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, C.c_void_p]),
+    "uni_pack_weight_h2": (c_i, [C.c_void_p, c_i, c_i, c_i, c_i, C.c_void_p, C.POINTER(C.c_float)]),
+    "uni_gemm_h2": (c_i, [c_f, c_i, c_f, C.c_float, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i,
+                          c_f, c_i, c_f, c_i, c_i, C.c_void_p]),
+    "uni_cast_h2": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, C.c_void_p]),
     "uni_layernorm": (c_i, [c_f, c_i, c_f, c_f, C.c_float, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_dwconv7_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_f, C.c_void_p]),
     "uni_groupnorm_act": (c_i, [c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),

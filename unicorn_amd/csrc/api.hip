@@ -1,4 +1,5 @@
 // extern "C" surface of libunicorn_hip.so (declared in include/unicorn_hip.h).
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -34,12 +35,12 @@ uni_ctx* uni_ctx_create(int device_id, const uni_model_cfg* cfg) {
     }
     for (int i = 0; i < 4; ++i)
         if (cfg->dims[i] <= 0 || cfg->dims[i] % 8 || cfg->depths[i] < 0) { uni_set_error("bad cfg dims/depths"); return nullptr; }
-    if (cfg->precision != 0 && cfg->precision != 1) { uni_set_error("precision %d unknown (0 = bf16, 1 = fp32)", cfg->precision); return nullptr; }
+    if (cfg->precision < 0 || cfg->precision > 2) { uni_set_error("precision %d unknown (0 = bf16, 1 = fp32, 2 = f16x2)", cfg->precision); return nullptr; }
     if (cfg->embed_dim != 128) { uni_set_error("embed_dim %d unsupported (128)", cfg->embed_dim); return nullptr; }
     uni_ctx* c = new uni_ctx();
     c->device = device_id;
     c->cfg = *cfg;
-    c->b32 = cfg->precision == 1;
+    c->b32 = cfg->precision;      // ActFmt
     return c;
 }
 void uni_ctx_destroy(uni_ctx* ctx) { engine_destroy(ctx); }
@@ -182,6 +183,36 @@ int uni_gemm_bf16(const uint16_t* A, int lda, const uint16_t* w_packed, int M, i
     g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
     g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg; g.dbg = force_cfg / 1000;
     API(launch_gemm(g, S(stream)));
+}
+int uni_pack_weight_h2(const float* w, int N, int Cin, int KH, int KW, void* out, float* wscale_out) {
+    UNI_REQUIRE(w && out && wscale_out && N > 0 && Cin > 0, "pack_weight_h2: bad argument");
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)N * Cin * KH * KW; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    const float scale = h2_weight_scale(mx);
+    pack_weight_h2_host(w, N, Cin, KH, KW, nullptr, scale, reinterpret_cast<uint16_t*>(out), cdiv(N, 256) * 256, cdiv(Cin * KH * KW, 64) * 64);
+    *wscale_out = 1.f / scale;
+    return 0;
+}
+int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int M, int N, int Hin, int Win, int Cin, int KH, int KW,
+                int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF, int ldf,
+                void* outB, int ldb, double* gn_stats, int cpg, int force_cfg, uni_stream_t stream) {
+    UNI_REQUIRE(A && w_packed && (outF || outB), "gemm_h2: NULL argument");
+    GemmArgs g;
+    g.A = reinterpret_cast<const bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const bf16*>(w_packed);
+    g.N = N; g.K = Cin * KH * KW; g.Kpad = cdiv(g.K, 64) * 64;
+    g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    const int Hout = (Hin + 2 * pad - KH) / stride + 1;
+    g.Wout = (Win + 2 * pad - KW) / stride + 1;
+    g.M = Hout * g.Wout;
+    UNI_REQUIRE(g.M == M, "gemm_h2: M=%d does not match conv geometry (%d)", M, g.M);
+    g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
+    g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
+    g.b32 = FMT_H2; g.wscale = wscale;
+    API(launch_gemm(g, S(stream)));
+}
+int uni_cast_h2(const float* x, int ldx, void* out, int ldo, int M, int C, uni_stream_t stream) {
+    UNI_REQUIRE(x && out, "cast_h2: NULL argument");
+    API(launch_cast_bf16(x, ldx, reinterpret_cast<bf16*>(out), ldo, M, C, S(stream), FMT_H2));
 }
 int uni_cast_bf16(const float* x, int ldx, uint16_t* out, int ldo, int M, int C, uni_stream_t stream) {
     UNI_REQUIRE(x && out, "cast: NULL argument");

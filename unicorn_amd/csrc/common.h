@@ -67,23 +67,57 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// "act" buffers hold GEMM operands: bf16 (es=2) in the default precision, fp32 (es=4) in the exact-fp32 mode.
-// idx is in ELEMENTS; b32 is wave-uniform.
-__device__ __forceinline__ void act_store4(void* base, size_t idx, float a, float b, float c, float d, int b32) {
-    if (b32) {
+// "act" buffers hold GEMM operands.  Three formats (wave-uniform `fmt`, historically named b32 in the arg structs):
+//   FMT_BF16  bf16 elements (2 B)                                   - 1 MFMA per product
+//   FMT_F32   fp32 elements (4 B), v_mfma_f32_32x32x2_f32           - exact, 1/16 of the bf16 MFMA rate
+//   FMT_H2    "f16x2": every fp32 value x is split into hi = f16(x), lo = f16(x - hi) (22 significand bits); a group of
+//             8 consecutive channels occupies 32 B: [8 x hi f16][8 x lo f16], so a 16-B LDS chunk is directly one
+//             v_mfma_f32_32x32x16_f16 operand and the GEMM issues hi.hi + hi.lo + lo.hi (3 MFMAs per product, fp32
+//             accumulate; the dropped lo.lo term is <= 2^-22 relative).  4 B per element like fp32, so element-index
+//             arithmetic (ld, column offsets: multiples of 8) is the fp32 one.  oracle/error_budget.py shows this is the
+//             narrowest operand format that keeps box IoU >= 0.999 on every stage (profiles/r02_precision_budget.json).
+// idx is in ELEMENTS.
+enum ActFmt { FMT_BF16 = 0, FMT_F32 = 1, FMT_H2 = 2 };
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+__device__ __forceinline__ void h2_split(float x, f16& hi, f16& lo) {
+    const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);     // keep hi finite; lo then extends the range to 2 x 65504
+    hi = (f16)c;
+    lo = (f16)(x - (float)hi);
+}
+__device__ __forceinline__ char* h2_addr(void* base, size_t idx) {      // byte address of the hi half of element idx
+    return reinterpret_cast<char*>(base) + (idx >> 3) * 32 + (idx & 7) * 2;
+}
+__device__ __forceinline__ void act_store4(void* base, size_t idx, float a, float b, float c, float d, int fmt) {
+    if (fmt == FMT_F32) {
         f32x4 o = {a, b, c, d};
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = o;
+    } else if (fmt == FMT_H2) {
+        const float x4[4] = {a, b, c, d};
+        f16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f16 hh, ll; h2_split(x4[j], hh, ll); h[j] = hh; l[j] = ll; }
+        char* p = h2_addr(base, idx);
+        *reinterpret_cast<f16x4*>(p) = h;
+        *reinterpret_cast<f16x4*>(p + 16) = l;
     } else {
         bf16x4 o = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + idx) = o;
     }
 }
-__device__ __forceinline__ void act_store8(void* base, size_t idx, const float (&v)[8], int b32) {
-    if (b32) {
+__device__ __forceinline__ void act_store8(void* base, size_t idx, const float (&v)[8], int fmt) {
+    if (fmt == FMT_F32) {
         f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
         float* p = reinterpret_cast<float*>(base) + idx;
         *reinterpret_cast<f32x4*>(p) = o0;
         *reinterpret_cast<f32x4*>(p + 4) = o1;
+    } else if (fmt == FMT_H2) {
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f16 hh, ll; h2_split(v[j], hh, ll); h[j] = hh; l[j] = ll; }
+        char* p = reinterpret_cast<char*>(base) + idx * 4;              // idx % 8 == 0
+        *reinterpret_cast<f16x8*>(p) = h;
+        *reinterpret_cast<f16x8*>(p + 16) = l;
     } else {
         bf16x8 o;
 #pragma unroll
@@ -91,10 +125,17 @@ __device__ __forceinline__ void act_store8(void* base, size_t idx, const float (
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + idx) = o;
     }
 }
-__device__ __forceinline__ void act_store1(void* base, size_t idx, float a, int b32) {
-    if (b32) reinterpret_cast<float*>(base)[idx] = a;
-    else reinterpret_cast<bf16*>(base)[idx] = (bf16)a;
+__device__ __forceinline__ void act_store1(void* base, size_t idx, float a, int fmt) {
+    if (fmt == FMT_F32) reinterpret_cast<float*>(base)[idx] = a;
+    else if (fmt == FMT_H2) {
+        f16 h, l;
+        h2_split(a, h, l);
+        char* p = h2_addr(base, idx);
+        *reinterpret_cast<f16*>(p) = h;
+        *reinterpret_cast<f16*>(p + 16) = l;
+    } else reinterpret_cast<bf16*>(base)[idx] = (bf16)a;
 }
+static inline int act_elem_bytes(int fmt) { return fmt == FMT_BF16 ? 2 : 4; }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

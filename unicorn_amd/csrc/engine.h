@@ -10,7 +10,7 @@
 #define UNI_STATS_SLOTS 1024
 
 struct HostParam { std::vector<int64_t> shape; std::vector<float> data; };
-struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, KH = 1, KW = 1, Cin = 0, b32 = 0; };
+struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, KH = 1, KW = 1, Cin = 0, b32 = 0; float wscale = 1.f; };
 struct PAffine { float* g = nullptr; float* b = nullptr; };
 struct PBlock { float* dw_w = nullptr; float* dw_b = nullptr; PAffine ln; PConv pw1, pw2; int C = 0; };
 struct PBaseConv { PConv conv; PAffine gn; int k = 1, stride = 1; };
@@ -26,7 +26,7 @@ struct uni_ctx {
     std::vector<float> zeros;
     std::vector<void*> dev_allocs;
     bool finalized = false, failed = false;
-    int b32 = 0;   // precision mode: 0 = bf16 MFMA operands, 1 = exact fp32 (v_mfma_f32_32x32x2_f32)
+    int b32 = 0;   // precision mode = operand format (ActFmt): 0 = bf16 MFMA operands, 1 = exact fp32 (v_mfma_f32_32x32x2_f32), 2 = split f16 ("f16x2", fp32-equivalent)
     // ConvNeXt
     float* stem_w = nullptr; float* stem_b = nullptr; PAffine stem_ln;
     PAffine ds_ln[4]; PConv ds_conv[4];

@@ -104,7 +104,27 @@ static PConv pack_convs(uni_ctx* c, const std::vector<ConvSrc>& srcs, int Cin, i
         n0 += s.N;
     }
     p.b32 = c->b32;
-    if (c->b32) {   // exact-fp32 mode: same [Npad][Kpad] (ky,kx,c) layout, fp32 elements
+    if (c->b32 == FMT_H2) {   // split-f16 mode: [Npad][Kpad] x (hi, lo) f16 in 32-byte groups of 8 k, one power-of-two scale per packed tensor
+        float mx = 0.f;
+        for (auto& s : srcs) {
+            const float* w = host_param(c, s.w, (size_t)s.N * p.K);
+            if (w)
+                for (int n = 0; n < s.N; ++n) {
+                    const float sc = s.row_scale ? fabsf(s.row_scale[n]) : 1.f;
+                    for (int k = 0; k < p.K; ++k) mx = std::max(mx, sc * fabsf(w[(size_t)n * p.K + k]));
+                }
+        }
+        const float scale = h2_weight_scale(mx);
+        p.wscale = 1.f / scale;
+        std::vector<uint16_t> ph((size_t)Npad * p.Kpad * 2, 0);
+        int r0 = 0;
+        for (auto& s : srcs) {
+            const float* w = host_param(c, s.w, (size_t)s.N * p.K);
+            if (w) pack_weight_h2_host(w, s.N, Cin, KH, KW, s.row_scale, scale, ph.data() + (size_t)r0 * p.Kpad * 2, s.N, p.Kpad);
+            r0 += s.N;
+        }
+        p.W = reinterpret_cast<bf16*>(dev_upload<uint16_t>(c, ph.data(), ph.size()));
+    } else if (c->b32 == FMT_F32) {   // exact-fp32 mode: same [Npad][Kpad] (ky,kx,c) layout, fp32 elements
         std::vector<float> pf((size_t)Npad * p.Kpad, 0.f);
         int r0 = 0;
         for (auto& s : srcs) {
@@ -360,7 +380,7 @@ static int prof_run(uni_ctx* c, int cls, double work, hipStream_t s, F&& f) {
 }
 static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
     if (c->prof_on) {   // algorithmic bytes: input map + weights + every output/residual stream, each once
-        const double es = g.b32 ? 4.0 : 2.0;
+        const double es = act_elem_bytes(g.b32);
         c->prof_bytes += (double)g.Hin * g.Win * g.Cin * es + (double)g.N * g.K * es +
                          (double)g.M * g.N * ((g.outF ? 4.0 : 0.0) + (g.outB ? es : 0.0) + (g.res ? 4.0 : 0.0));
     }
@@ -421,7 +441,7 @@ struct ActPtr {
     operator bf16*() const { return reinterpret_cast<bf16*>(p); }
     bool operator==(const ActPtr& o) const { return p == o.p; }
 };
-static ActPtr actalloc(uni_ctx* c, size_t n) { return ActPtr(wsalloc<char>(c, n * (c->b32 ? 4 : 2)), c->b32 ? 4 : 2); }
+static ActPtr actalloc(uni_ctx* c, size_t n) { const int es = act_elem_bytes(c->b32); return ActPtr(wsalloc<char>(c, n * es), es); }
 
 struct Out {
     float* F = nullptr; int ldf = 0;
@@ -437,7 +457,7 @@ static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, i
     g.Mper = Hout * Wout; g.M = B * g.Mper; g.N = p.N; g.K = p.K; g.Kpad = p.Kpad;
     g.Hin = Hin; g.Win = Win; g.Cin = p.Cin; g.KH = p.KH; g.KW = p.KW; g.stride = stride; g.pad = pad; g.Wout = Wout;
     g.bias = p.bias;
-    g.b32 = p.b32;
+    g.b32 = p.b32; g.wscale = p.wscale;
     return g;
 }
 

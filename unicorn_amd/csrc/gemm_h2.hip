@@ -1,0 +1,308 @@
+// K1b / K2 / K5 in the "f16x2" precision mode: fp32-EQUIVALENT implicit GEMM on the f16 MFMA pipe.
+//
+//   out[m][n] = epilogue( wscale * sum_k A[m][k] * W[n][k] )
+//
+// Both operands are stored split: x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significand bits; FMT_H2 in
+// common.h: per 8 consecutive k a 32-byte group [8 x hi][8 x lo]).  Every product is evaluated as
+//     hi.hi + hi.lo + lo.hi           (3 x v_mfma_f32_32x32x16_f16, each partial product exact in fp32, fp32 accumulate)
+// and the dropped lo.lo term is <= 2^-22 relative: the result is in the error class of an fp32 fmaf chain at 3/16 of
+// the MFMA time of the exact v_mfma_f32_32x32x2_f32 path (16 x the bf16 cost).  Why this format and not bf16 or bf16x2:
+// oracle/error_budget.py / profiles/r02_precision_budget.json (box IoU >= 0.999 needs >= ~20 operand bits on EVERY
+// stage with the synthetic weights; bf16x2 = 16 bits misses it, f16x2 passes on tiny and large).
+// Weights are pre-scaled by a power of two per packed tensor (GemmArgs::wscale undoes it) so their lo halves stay in
+// the normal f16 range; activations need no scaling (hi is clamped to +-65504, lo extends the range to 2 x that).
+//
+// Kernel structure = gemm.hip's: LDS-DMA double buffer (global_load_lds_dwordx4, source-side XOR swizzle), one barrier
+// per K step, swapped MFMA operands, shared epilogue (gemm_epi.h).  A K step covers 32 k (128-byte LDS rows, the same
+// geometry as the 64-k bf16 rows): chunk 2c of a row holds the hi halves of k = 8c..8c+7, chunk 2c+1 the lo halves.
+// Per step and wave tile (64 x 64): 16 ds_read_b128 feed 24 MFMAs (bf16: 16 feed 16), i.e. the split kernel is closer to
+// MFMA-bound than the bf16 one.
+#include "kernels.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+__device__ u32x4 g_zero_page_h2 = {0u, 0u, 0u, 0u};
+
+#define GLDS16H(gptr, lptr)                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#define OPAQUE64H(x)                                     \
+    do {                                                 \
+        int _lo = (int)(x), _hi = (int)((x) >> 32);      \
+        asm volatile("" : "+v"(_lo), "+v"(_hi));         \
+        (x) = ((long)_hi << 32) | (unsigned)_lo;         \
+    } while (0)
+
+#include "gemm_epi.h"
+
+template <int WM, int WN, int TM, int TN, bool CONV, bool STATS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_h2_kernel(GemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int BKE = 32;                  // k per step
+    constexpr int ROWB = 128;                // LDS row bytes = BKE x (2 B hi + 2 B lo)
+    constexpr int RPP = 8;                   // rows per 1-KiB DMA piece
+    constexpr int A_PC = BM / RPP / NW, B_PC = BN / RPP / NW;
+    static_assert(A_PC >= 1 && B_PC >= 1, "tile too small for the wave grid");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                   // [2][BM][128 B]
+    char* Bs = smem + 2 * BM * ROWB;                   // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nbn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int L;
+    {   // XCD-aware bijective block remap (block b runs on XCD b % 8)
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    int bm, bn;
+    {   // super-tile order: chunks of 8 N tiles, M-major inside a chunk (see gemm.hip)
+        const int nbm = (p.M + BM - 1) / BM;
+        constexpr int GN = 8;
+        const int per_chunk = nbm * GN;
+        const int c = L / per_chunk;
+        const int wc = min(GN, nbn - c * GN);
+        const int rem = L - c * per_chunk;
+        bm = rem / wc;
+        bn = c * GN + rem - bm * wc;
+    }
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- per-lane DMA sources: lane -> row lane/8 of its piece, physical chunk lane%8, logical chunk = phys ^ ((row>>1)&7);
+    // logical chunk lc -> k group lc>>1 (8 k), half lc&1 (0 = hi, 1 = lo)
+    const int lrow = lane >> 3;
+    const int lch = (lane & 7) ^ (((RPP * wave + lrow) >> 1) & 7);
+    const int kgrp = lch >> 1, half = lch & 1;
+    const char* abase = reinterpret_cast<const char*>(p.A);
+    const long zoff = reinterpret_cast<const char*>(&g_zero_page_h2) - abase;
+    int a_pix[A_PC];
+#pragma unroll
+    for (int i = 0; i < A_PC; ++i) {
+        int m = m0 + RPP * (wave + NW * i) + lrow;
+        m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            int b = m / p.Mper, q = m - b * p.Mper;
+            int oy = q / p.Wout, ox = q - oy * p.Wout;
+            a_pix[i] = (b << 24) | (oy << 12) | ox;
+        } else {
+            a_pix[i] = m;
+        }
+    }
+    const char* wbase = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + RPP * wave + lrow) * p.Kpad) * 4 + lch * 16;
+
+    auto issue = [&](int kt, int buf) {
+        const int k = kt * BKE + kgrp * 8;                 // first of this lane's 8 k
+        const bool kok = k < p.K;
+        char* adst = As + buf * BM * ROWB + wave * 1024;
+        char* bdst = Bs + buf * BN * ROWB + wave * 1024;
+        if (CONV) {
+            int tap = k / p.Cin;
+            int c = k - tap * p.Cin;
+            int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+            for (int i = 0; i < A_PC; ++i) {
+                int bb = a_pix[i] >> 24, oy = (a_pix[i] >> 12) & 0xfff, ox = a_pix[i] & 0xfff;
+                int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                bool ok = kok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                long off = ok ? (long)(((size_t)((bb * p.Hin + iy) * p.Win + ix) * p.lda + c) * 4 + half * 16) : zoff;
+                OPAQUE64H(off);
+                GLDS16H(abase + off, adst + i * NW * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PC; ++i) {
+                long off = kok ? (long)(((size_t)a_pix[i] * p.lda + k) * 4 + half * 16) : zoff;
+                OPAQUE64H(off);
+                GLDS16H(abase + off, adst + i * NW * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PC; ++i) GLDS16H(wbase + ((size_t)i * NW * RPP * p.Kpad + (size_t)kt * BKE) * 4, bdst + i * NW * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BKE - 1) / BKE;              // the packed weights are zero beyond K (Kpad >= roundup(K, 64))
+    const int fr = lane & 31, fh = lane >> 5;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __syncthreads();                                   // K slice kt landed (vmcnt(0) + barrier); everyone is done with buf^1
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        const char* a = As + buf * BM * ROWB;
+        const char* b = Bs + buf * BN * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                   // 16 k per MFMA; lane half fh carries k = 16 kk + 8 fh + (0..7)
+            const int ch = 2 * (2 * kk + fh);              // logical chunk of the hi halves; +1 = lo halves
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * 32 * TM + i * 32 + fr, sw = (row >> 1) & 7;
+                ah[i] = *reinterpret_cast<const f16x8*>(a + row * ROWB + ((ch ^ sw) << 4));
+                al[i] = *reinterpret_cast<const f16x8*>(a + row * ROWB + (((ch + 1) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * 32 * TN + j * 32 + fr, sw = (row >> 1) & 7;
+                bh[j] = *reinterpret_cast<const f16x8*>(b + row * ROWB + ((ch ^ sw) << 4));
+                bl[j] = *reinterpret_cast<const f16x8*>(b + row * ROWB + (((ch + 1) ^ sw) << 4));
+            }
+            // swapped operands (weights = MFMA A): lane -> pixel row, 4 consecutive channels per accumulator quad
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (p.wscale != 1.f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.wscale;
+    }
+    gemm_epilogue<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+template <int WM, int WN, int TM, int TN, bool CONV>
+static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+    size_t lds = (size_t)2 * (BM + BN) * 128;
+    if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
+    if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (a.stats) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    return 0;
+}
+
+// called by launch_gemm (gemm.hip) for FMT_H2 problems after the common argument checks
+int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    UNI_REQUIRE(a.K % 8 == 0 && a.Kpad % 32 == 0 && a.lda % 8 == 0, "gemm(h2): K=%d Kpad=%d lda=%d", a.K, a.Kpad, a.lda);
+    if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 4096 && a.Mper / a.Wout < 4096, "gemm(h2): conv K mismatch / map too large");
+    if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64 && a.act == ACT_NONE, "gemm(h2): cpg=%d / activation with GroupNorm statistics", a.cpg);
+    if (a.outB) UNI_REQUIRE(a.N % 8 == 0 && a.ldb % 8 == 0 && ((uintptr_t)a.outB & 31) == 0, "gemm(h2): operand-format output needs N, ldb multiples of 8");
+    {
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        a.epi = (a.N % 8 == 0) && (!a.bias || al16(a.bias)) && (!a.res || (a.ldr % 4 == 0 && al16(a.res))) &&
+                (!a.outF || (a.ldf % 4 == 0 && al16(a.outF))) && (!a.outB || a.ldb % 8 == 0);
+    }
+    // tile choice: same reasoning as the bf16 kernel (largest tile that still gives >= ~1.5 blocks per CU); a step of the
+    // split kernel carries 3x the MFMA work per byte, so the 256 x 256 tile pays off from fewer blocks on
+    const long b44 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
+    const long b22 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    const long b21 = (long)cdiv(a.M, 128) * cdiv(a.N, 64);
+    const long b12 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
+    const double util44 = (double)a.N / (cdiv(a.N, 256) * 256.0);
+    int cfg = a.force_cfg % 1000;
+    if (cfg == 0) {
+        if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
+        else if (util44 >= 0.74 && b44 >= 384 && a.epi) cfg = 44;
+        else if (b22 >= 400) cfg = 22;
+        else if (conv) cfg = b12 >= 400 ? 12 : 11;
+        else cfg = b21 >= 400 ? 21 : 11;
+    }
+    if (!a.epi && cfg == 44) cfg = 22;
+#define GOH(WM, WN, TM, TN) return conv ? launch_h2_cfg<WM, WN, TM, TN, true>(a, s) : launch_h2_cfg<WM, WN, TM, TN, false>(a, s)
+    switch (cfg) {
+        case 44: GOH(4, 4, 2, 2);     // 256 x 256, 16 waves, 128 KiB LDS
+        case 22: GOH(2, 2, 2, 2);     // 128 x 128
+        case 12: GOH(2, 2, 1, 2);     // 64 x 128
+        case 21: GOH(2, 2, 2, 1);     // 128 x 64
+        default: GOH(2, 2, 1, 1);     // 64 x 64
+    }
+#undef GOH
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side packing: OIHW fp32 -> [Npad][Kpad] FMT_H2 (k = (ky*KW + kx)*Cin + c), pre-scaled by `scale` (a power of two)
+// ------------------------------------------------------------------------------------------------
+uint16_t f32_to_f16_host(float f) {      // round-to-nearest-even, subnormals kept, overflow -> +-65504 (never inf)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t mag = u & 0x7fffffffu;
+    if (mag > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                  // NaN
+    if (mag >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);                 // >= 65520 rounds past the largest finite half
+    if (mag < 0x33000001u) return (uint16_t)sign;                              // <= 2^-25: rounds to zero
+    const int e = (int)(mag >> 23) - 127;
+    uint32_t man = (mag & 0x7fffffu) | 0x800000u;                              // 24-bit significand
+    int shift;                                                                 // bits to drop
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }                         // subnormal half: value = man * 2^(e-23) / 2^-24
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; man &= 0x7fffffu; }
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;                    // RNE (a carry out of the mantissa bumps the exponent: correct)
+    return (uint16_t)(sign | (base + q));
+}
+float f16_to_f32_host(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = (float)m * 5.9604644775390625e-8f;                         // m * 2^-24
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else { uint32_t u = ((uint32_t)(e + 112) << 23) | (m << 13); memcpy(&v, &u, 4); }
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u |= sign;
+    memcpy(&v, &u, 4);
+    return v;
+}
+void pack_weight_h2_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, float scale, uint16_t* out,
+                         int Npad, int Kpad) {
+    const int K = KH * KW * Cin;
+    memset(out, 0, (size_t)Npad * Kpad * 4);
+    for (int n = 0; n < N; ++n) {
+        const float sc = (row_scale ? row_scale[n] : 1.f);
+        uint16_t* o = out + (size_t)n * Kpad * 2;
+        const float* wn = w + (size_t)n * K;
+        for (int c = 0; c < Cin; ++c)
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int k = (ky * KW + kx) * Cin + c;
+                    const float x = sc * wn[(c * KH + ky) * KW + kx] * scale;
+                    const uint16_t hi = f32_to_f16_host(x);
+                    const uint16_t lo = f32_to_f16_host(x - f16_to_f32_host(hi));
+                    o[(k >> 3) * 16 + (k & 7)] = hi;
+                    o[(k >> 3) * 16 + 8 + (k & 7)] = lo;
+                }
+    }
+}
+// power-of-two scale that puts max |w| just below 2^15 (hi halves finite, lo halves of all but negligible weights normal)
+float h2_weight_scale(float maxabs) {
+    if (!(maxabs > 0.f) || !std::isfinite(maxabs)) return 1.f;
+    int e;
+    (void)frexpf(maxabs, &e);               // maxabs = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.f, 15 - e);             // maxabs * scale in [2^14, 2^15)
+}

@@ -307,7 +307,7 @@ static int launch_pipe_inst(const GemmArgs& a, int grid, hipStream_t s) {
 
 bool gemm_pipe_supported(const GemmArgs& a) {
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
-    return !conv && !a.stats && !a.b32 && a.epi && a.K == a.Kpad && a.bias && a.act_col0 == 0 && a.out_hw == 0 &&
+    return !conv && !a.stats && a.b32 == FMT_BF16 && a.epi && a.K == a.Kpad && a.bias && a.act_col0 == 0 && a.out_hw == 0 &&
            (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_GELU) && (a.outF || a.outB) && (a.outF || !a.res);
 }
 

@@ -19,11 +19,18 @@ struct GemmArgs {
     bf16* outB = nullptr; int ldb = 0;
     double* stats = nullptr; int cpg = 0;     // GroupNorm group sums [G][2] of (acc+bias), cpg = channels/group
     int force_cfg = 0;                        // 0 = heuristic, else 22 / 12 / 21 / 11
-    int b32 = 0;                              // exact-fp32 mode: A, W and outB are fp32 (v_mfma_f32_32x32x2_f32)
+    int b32 = 0;                              // operand format (ActFmt): FMT_BF16, FMT_F32 (A, W, outB fp32; v_mfma_f32_32x32x2_f32) or FMT_H2 (split f16, gemm_h2.hip)
+    float wscale = 1.f;                       // FMT_H2: the packed weights carry a power-of-two scale; the accumulator is multiplied by wscale
     int dbg = 0;                              // ablation switches for tools/gemm_bench.py (1 = no DMA after tile 0, 2 = no MFMA)
     int epi = 0;                              // set by launch_gemm: 1 = LDS-staged, row-coalesced epilogue stores
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+int launch_gemm_h2(const GemmArgs& a, hipStream_t s);     // gemm_h2.hip (reached through launch_gemm when a.b32 == FMT_H2)
+uint16_t f32_to_f16_host(float f);
+float f16_to_f32_host(uint16_t h);
+float h2_weight_scale(float maxabs);
+void pack_weight_h2_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, float scale, uint16_t* out,
+                         int Npad, int Kpad);
 int launch_gemm_pipe(const GemmArgs& a, hipStream_t s);
 bool gemm_pipe_supported(const GemmArgs& a);
 int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persistent 256x256 tiles, next tile prefetched before the drain

@@ -17,6 +17,7 @@ import torch
 from .. import _lib as L
 from ..ops import condinst_masks, empty_nhwc, nhwc
 
+PRECISIONS = {"bf16": 0, "fp32": 1, "f16x2": 2}      # uni_model_cfg.precision
 _IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 # exps/default/*.py + unicorn/exp/unicorn_track.py:31-113, unicorn_track_mask.py:31-47
@@ -122,10 +123,14 @@ class UnicornHeadMask(UnicornHead):
 
 class Unicorn:
     def __init__(self, name_or_cfg="unicorn_track_tiny", device=None, precision="bf16"):
-        """precision: "bf16" (MFMA bf16 operands, fp32 accumulate; the benchmark configuration) or "fp32" (exact-fp32
-        MFMA everywhere; the parity mode that meets box IoU >= 0.999 against the fp32 reference)."""
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        """precision (operand format of every dense contraction; accumulation, residual stream and statistics are fp32):
+          "f16x2"  fp32-equivalent: operands split into hi + lo f16 halves, 3 f16 MFMAs per product (22 operand bits).
+                   Meets box/mask IoU >= 0.999 and embedding cosine within 1e-4 against the fp32 reference: parity mode.
+          "fp32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain; 16x the bf16 MFMA cost.
+          "bf16"   bf16 operands, 1 MFMA per product; fastest, embedding cosine still within 1e-4 but box IoU is NOT
+                   (8 operand bits; profiles/r02_precision_budget.json)."""
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (sorted(PRECISIONS),))
         self.precision = precision
         cfg = dict(MODEL_CONFIGS[name_or_cfg]) if isinstance(name_or_cfg, str) else dict(name_or_cfg)
         self.cfg_name = name_or_cfg if isinstance(name_or_cfg, str) else "custom"
@@ -162,7 +167,7 @@ class Unicorn:
             c.depths[:] = self.depths
             c.num_classes, c.mask, c.n_layer_att = self.num_classes, int(self.mask), self.n_layer_att
             c.embed_dim, c.up_rate, c.d_rate = self.embed_dim, self.up_rate, self.d_rate
-            c.precision = 1 if self.precision == "fp32" else 0
+            c.precision = PRECISIONS[self.precision]
             ctx = L.lib().uni_ctx_create(idx, C.byref(c))
             if not ctx:
                 raise L.UnicornHipError("uni_ctx_create: %s" % L.lib().uni_last_error().decode())
