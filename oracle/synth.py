@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE (also used by bench.py to fill the model with weights of the right shape).
 `param_spec(cfg)` restates the reference state-dict layout (names + shapes; checked against the real
-reference in tests/test_oracle_vs_reference.py and against tests/golden/state_spec_*.json);
+reference models through tests/golden/state_spec_*.json, dumped by tests/golden/make_golden.py);
 `synth_state_dict(cfg)` fills every tensor from a per-name seeded generator so the build container
 (real reference) and the GPU box (oracle + HIP path) see bit-identical weights without shipping them.
 """

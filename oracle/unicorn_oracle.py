@@ -8,8 +8,8 @@ the product package ``unicorn_amd`` never does (it fails loudly when the HIP lib
 Parity pin: ``tests/golden/*.npz`` were produced by the REAL reference modules imported in the
 build container (``tests/golden/make_golden.py`` via ``oracle/ref_bootstrap.py``) with the
 synthetic weights of ``oracle/synth.py``; ``tests/test_oracle_golden.py`` checks this file against
-them, and ``tests/test_oracle_vs_reference.py`` re-runs the comparison live whenever
-``/root/reference`` is present.  Third-party arithmetic not under /root/reference
+them (re-generate with ``python tests/golden/make_golden.py`` wherever ``/root/reference`` is present: the arrays are
+bit-reproducible).  Third-party arithmetic not under /root/reference
 (torchvision nms/batched_nms, pinned 0.11.x by assets/install.md:8,14) is restated from its
 published semantics; the reference has no test pinning NMS results -> that part is "parity
 unpinned" (SURVEY.md §8c).
@@ -494,13 +494,16 @@ def postprocess_inst(cfg: ModelCfg, head_out, num_classes, conf_thre, nms_thre, 
 
 
 def sample_instance_embeddings(embed: Tensor, boxes_xyxy: Tensor, stride: int = 8) -> Tensor:
-    """evaluators/mot_evaluator.py:1024-1034: bilinear grid_sample of the embedding map at box centres
-    (border padding, align_corners=False). embed (1,C,H,W), boxes in input-image pixels -> (N,C)."""
+    """evaluators/mot_evaluator.py:1024-1034 (also :822-827): bilinear grid_sample of the embedding map at box centres
+    (border padding, align_corners=False).  The reference normalises the clamped stride-8 centre by (W8 - 1) and then
+    samples with align_corners=False, i.e. at x = clamp(c/s - 0.5, 0, W8-1) * W8/(W8-1) - 0.5; restated literally
+    (pinned by tests/golden/sample_embed_ref.npz, produced by exec-ing those reference lines).
+    embed (1,C,H,W), boxes in input-image pixels -> (N,C)."""
     _, C, H, W = embed.shape
-    cx = (boxes_xyxy[:, 0] + boxes_xyxy[:, 2]) / 2
-    cy = (boxes_xyxy[:, 1] + boxes_xyxy[:, 3]) / 2
-    gx = cx / (W * stride) * 2 - 1
-    gy = cy / (H * stride) * 2 - 1
+    s = stride
+    cx, cy = (boxes_xyxy[:, 0] + boxes_xyxy[:, 2]) / 2 / s - 0.5, (boxes_xyxy[:, 1] + boxes_xyxy[:, 3]) / 2 / s - 0.5
+    gx = (torch.clamp(cx, min=0, max=W - 1) / (W - 1) - 0.5) * 2.0
+    gy = (torch.clamp(cy, min=0, max=H - 1) / (H - 1) - 0.5) * 2.0
     grid = torch.stack((gx, gy), -1).view(1, -1, 1, 2)
     return F.grid_sample(embed, grid, mode="bilinear", padding_mode="border", align_corners=False)[0, :, :, 0].t()
 

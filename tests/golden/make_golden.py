@@ -114,13 +114,15 @@ def run_sot(exp_name, H, W):
         out["n_det_mot"] = np.array([0 if det is None else det.shape[0]])
         if det is not None:
             pack(out, "det_mot", det[:64])
-            # instance embeddings at box centres (mot_evaluator.py:1024-1034)
-            embs = []
-            for b in det[:16]:
-                cx, cy = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2
-                grid = torch.tensor([[[[cx / W * 2 - 1, cy / H * 2 - 1]]]])
-                embs.append(F.grid_sample(e_cur, grid, mode="bilinear", padding_mode="border",
-                                          align_corners=False)[0, :, 0, 0])
+            # instance embeddings at box centres: the reference's own lines (mot_evaluator.py:1024-1034) exec'd verbatim
+            import textwrap
+            import types
+            src = open("/root/reference/unicorn/evaluators/mot_evaluator.py").read().split("\n")[1023:1034]
+            assert "cx, cy = (bboxes[:, 0] + bboxes[:, 2])/2/s - 0.5" in src[0] and "track_feats = torch.stack" in src[-1]
+            ns = {"torch": torch, "F": F, "bboxes": det[:16, :4].clone(), "s": 8, "embed_cur": e_cur,
+                  "self": types.SimpleNamespace(img_size=(H, W))}
+            exec("track_feat_list = []\n" + textwrap.dedent("\n".join(src)), ns)
+            embs = list(ns["track_feats"])
             pack(out, "inst_embed", torch.stack(embs))
     np.savez_compressed(os.path.join(HERE, "%s_%dx%d.npz" % (exp_name, H, W)), **out)
     print(exp_name, {k: v.shape for k, v in out.items() if not k.endswith("__shape") and not k.endswith("__stats")})

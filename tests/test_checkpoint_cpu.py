@@ -74,3 +74,20 @@ def test_load_checkpoint_file_unwraps_model_key(tmp_path):
     torch.save({"model": {"a": torch.ones(2)}, "start_epoch": 3}, p)
     m = Fake()
     assert ck.load_checkpoint_file(m, str(p)) == "ok" and list(m.sd) == ["a"]
+
+
+def test_load_state_dict_before_cuda_reports_keys_and_rejects_wrong_shapes():
+    """tools/track.py:176-188 order (load_state_dict, then .cuda()): the key report and `strict` must not depend on the order,
+    and a checkpoint of another configuration (nc = 1 vs nc = 8) raises like nn.Module does.  No device needed."""
+    from unicorn_amd.models import Unicorn
+    spec = ck.state_spec("unicorn_track_tiny")
+    sd = {k: torch.zeros(v) for k, v in spec.items()}
+    del sd["head.beta_1"]
+    sd["head.some_new_tensor"] = torch.zeros(3)
+    res = Unicorn("unicorn_track_tiny").load_state_dict(sd, strict=False)
+    assert list(res.missing_keys) == ["head.beta_1"] and list(res.unexpected_keys) == ["head.some_new_tensor"]
+    with pytest.raises(RuntimeError):
+        Unicorn("unicorn_track_tiny").load_state_dict(sd, strict=True)
+    sd = {k: torch.zeros(v) for k, v in ck.state_spec("unicorn_track_large_mot_challenge").items()}
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        Unicorn("unicorn_track_large").load_state_dict(sd, strict=False)

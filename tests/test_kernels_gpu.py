@@ -334,6 +334,10 @@ def test_sample_embeddings(L):
     got = sample_embeddings(emb.cuda(), boxes.cuda())
     assert torch.allclose(got.cpu(), ref, atol=1e-5)
     assert sample_embeddings(emb.cuda(), boxes[:0].cuda()).shape == (0, 128)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_embed_ref.npz"))
+    for tag in ("a", "b"):      # rows produced by exec-ing the reference's own lines (tests/golden/make_golden_sample.py)
+        got = sample_embeddings(torch.from_numpy(gold["embed_" + tag]).cuda(), torch.from_numpy(gold["boxes_" + tag]).cuda())
+        assert torch.allclose(got.cpu(), torch.from_numpy(gold["feats_" + tag]), atol=1e-5), tag
 
 
 def test_condinst_masks(L):
@@ -550,3 +554,12 @@ def test_gemm_h2_large_and_subnormal_lo(L):
         torch.cuda.synchronize()
         r = ((outF.double() - exp).abs() / (mag * 2.0 ** -20 + 1e-12)).max().item()
         assert r < 1.5, (cfg, r)
+
+
+def test_wrapper_error_paths_raise_unicorn_error(L):
+    """ops.postprocess_image / ops.letterbox reject wrong dtypes with UnicornHipError (callers catch that type)."""
+    from unicorn_amd.ops import letterbox, postprocess_image
+    with pytest.raises(L.UnicornHipError):
+        postprocess_image(torch.zeros(10, 6, device="cuda", dtype=torch.float64), 1, 0.1, 0.5)
+    with pytest.raises(L.UnicornHipError):
+        letterbox(torch.zeros(8, 8, 3, device="cuda", dtype=torch.float32), (32, 32))

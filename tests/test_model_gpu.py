@@ -373,3 +373,18 @@ def test_load_state_dict_reports_missing_and_unexpected():
     m2 = Unicorn("unicorn_track_tiny").cuda(0)
     with pytest.raises(RuntimeError):
         m2.load_state_dict(P, strict=True)
+    # reference order load -> cuda (tools/track.py:176-188): same report before the device exists, strict honoured,
+    # and a wrong-config checkpoint (nc = 1 into nc = 8) raises instead of running on zero-filled weights
+    m3 = Unicorn("unicorn_track_tiny")
+    res = m3.load_state_dict(P, strict=False)
+    assert list(res.missing_keys) == ["head.beta_1"] and list(res.unexpected_keys) == ["head.some_new_tensor"]
+    with pytest.raises(RuntimeError):
+        Unicorn("unicorn_track_tiny").load_state_dict(P, strict=True)
+    Pw = dict(synth.synth_state_dict(uo.CONFIGS["unicorn_track_tiny"]))
+    Pw["head.cls_preds.0.weight"] = Pw["head.cls_preds.0.weight"][:1]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        Unicorn("unicorn_track_tiny").load_state_dict(Pw, strict=False)
+    m3.cuda(0)
+    frames, _ = synth.synth_clip(64, 64, 1, seed=0)
+    fpn, _ = m3(imgs=frames[0].cuda(), mode="backbone")
+    assert torch.isfinite(fpn[0]).all()

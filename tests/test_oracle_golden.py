@@ -131,3 +131,11 @@ def test_postprocess_oracle_matches_reference_golden(A, nc, agn):
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess_planted.npz"))
     det = uo.postprocess(planted_pred(A, nc, seed=A + nc), nc, 0.2, 0.45, class_agnostic=agn)[0]
     assert np.array_equal(det.numpy(), gold["%d_%d_%d" % (A, nc, int(agn))])
+
+
+def test_sample_instance_embeddings_matches_reference_lines(golden_dir):
+    """mot_evaluator.py:1024-1034 exec'd from the reference tree (tests/golden/make_golden_sample.py) vs the oracle restatement."""
+    g = np.load(os.path.join(golden_dir, "sample_embed_ref.npz"))
+    for tag in ("a", "b"):
+        got = uo.sample_instance_embeddings(torch.from_numpy(g["embed_" + tag]), torch.from_numpy(g["boxes_" + tag]))
+        assert torch.allclose(got, torch.from_numpy(g["feats_" + tag]), atol=1e-6), tag

@@ -7,7 +7,7 @@
 #include "../../include/unicorn_hip.h"
 #include "kernels.h"
 
-#define UNI_STATS_SLOTS 1024
+#define UNI_STATS_SLOTS 4096     // GroupNorm statistics slots per stage call: one per (GroupNorm, sample); backbone_fpn has 36 GNs, the mask head 31, B <= 64
 
 struct HostParam { std::vector<int64_t> shape; std::vector<float> data; };
 struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, KH = 1, KW = 1, Cin = 0, b32 = 0; float wscale = 1.f; };

@@ -170,15 +170,19 @@ int launch_pos_embed(const float* row, const float* col, int sz, int nf, float* 
     return 0;
 }
 
-// evaluators/mot_evaluator.py:1024-1034: grid_sample(embed, box centre) bilinear, border, align_corners=False
+// evaluators/mot_evaluator.py:1024-1034 (same lines at :822-827): the box centre in stride-8 pixels, cx = c/s - 0.5, is clamped
+// to [0, W-1] and normalised by (W-1) (an align_corners=True style grid), then handed to grid_sample(align_corners=False,
+// border): the sampled position is therefore x = clamp(c/s - 0.5, 0, W-1) * W/(W-1) - 0.5, clipped to [0, W-1].  The float
+// expression order of the reference lines and of grid_sample's unnormalise is kept.
 __global__ void sample_embed_kernel(const float* emb, int H, int W, int C, const float* boxes, int ldbox, int n,
                                     float stride, float* out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * C) return;
     const int c = e % C, i = e / C;
     const float* b = boxes + (size_t)i * ldbox;
-    const float cx = (b[0] + b[2]) / 2, cy = (b[1] + b[3]) / 2;
-    const float gx = cx / (W * stride) * 2 - 1, gy = cy / (H * stride) * 2 - 1;
+    float cx = (b[0] + b[2]) / 2 / stride - 0.5f, cy = (b[1] + b[3]) / 2 / stride - 0.5f;
+    const float gx = (fminf(fmaxf(cx, 0.f), (float)(W - 1)) / (float)(W - 1) - 0.5f) * 2.0f;
+    const float gy = (fminf(fmaxf(cy, 0.f), (float)(H - 1)) / (float)(H - 1) - 0.5f) * 2.0f;
     float x = ((gx + 1) * W - 1) / 2, y = ((gy + 1) * H - 1) / 2;
     x = fminf(fmaxf(x, 0.f), (float)(W - 1));
     y = fminf(fmaxf(y, 0.f), (float)(H - 1));

@@ -208,12 +208,31 @@ class Unicorn:
         """Same contract as nn.Module.load_state_dict; keys follow the reference checkpoint namespace."""
         if self._ready:
             raise L.UnicornHipError("weights already loaded (the packed device copy is immutable)")
-        if self._ctx is None:
+        res = self._check_keys(state_dict, strict)          # spec-based, on the host: same answer before and after .cuda()
+        if self._ctx is None:                               # reference order is load -> cuda (tools/track.py:176-188): upload later
             self._pending_sd = state_dict
-            return _IncompatibleKeys([], [])
-        return self._load(state_dict, strict)
+            return res
+        self._load(state_dict)
+        return res
 
-    def _load(self, state_dict, strict=False):
+    def _check_keys(self, state_dict, strict):
+        """missing / unexpected keys against the reference model's parameter spec; a tensor whose SHAPE differs raises like
+        nn.Module.load_state_dict does (a wrong-config checkpoint must not run on zero weights)."""
+        from ..utils.checkpoint import state_spec      # names the reference model owns (buffers / foreign keys are "unexpected")
+        spec = state_spec(dict(dims=self.dims, depths=self.depths, num_classes=self.num_classes, mask=self.mask,
+                               n_layer_att=self.n_layer_att, embed_dim=self.embed_dim, up_rate=self.up_rate))
+        fl = {k: v for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
+        bad = ["%s: checkpoint %s vs model %s" % (k, tuple(v.shape), tuple(spec[k])) for k, v in fl.items()
+               if k in spec and tuple(v.shape) != tuple(spec[k])]
+        if bad:
+            raise RuntimeError("Error(s) in loading state_dict: size mismatch for " + "; ".join(bad[:8]))
+        missing = [k for k in spec if k not in fl]
+        unexpected = [k for k in fl if k not in spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict: missing keys %s, unexpected keys %s" % (missing[:8], unexpected[:8]))
+        return _IncompatibleKeys(missing, unexpected)
+
+    def _load(self, state_dict):
         lib = L.lib()
         for k, v in state_dict.items():
             if not torch.is_tensor(v) or not v.dtype.is_floating_point:
@@ -223,15 +242,8 @@ class Unicorn:
             L.check(lib.uni_ctx_load_param(self._ctx, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim), "load_param")
         nm = C.c_int(0)
         L.check(lib.uni_ctx_finalize(self._ctx, C.byref(nm)), "uni_ctx_finalize")
-        missing = [lib.uni_ctx_missing_name(self._ctx, i).decode() for i in range(nm.value)]
-        from ..utils.checkpoint import state_spec      # names the reference model owns (buffers / foreign keys are "unexpected")
-        spec = state_spec(dict(dims=self.dims, depths=self.depths, num_classes=self.num_classes, mask=self.mask,
-                               n_layer_att=self.n_layer_att, embed_dim=self.embed_dim, up_rate=self.up_rate))
-        unexpected = [k for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype.is_floating_point and k not in spec]
-        if strict and (missing or unexpected):
-            raise RuntimeError("Error(s) in loading state_dict: missing keys %s, unexpected keys %s" % (missing[:8], unexpected[:8]))
+        self._engine_missing = [lib.uni_ctx_missing_name(self._ctx, i).decode() for i in range(nm.value)]   # zero-filled by the engine
         self._ready = True
-        return _IncompatibleKeys(missing, unexpected)
 
     def _require_ready(self):
         if self._ctx is None:

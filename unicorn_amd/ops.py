@@ -126,7 +126,7 @@ def postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnost
     the read-back of M (the output shape is data dependent)."""
     _need_cuda(image_pred)
     if image_pred.dtype != torch.float32 or image_pred.stride(-1) != 1:
-        raise UnicornHipError("postprocess_image: needs a float32 (A, 5+nc) tensor with unit inner stride")
+        raise L.UnicornHipError("postprocess_image: needs a float32 (A, 5+nc) tensor with unit inner stride")
     A, ld = image_pred.shape[0], image_pred.stride(0) if image_pred.shape[0] > 1 else image_pred.shape[1]
     dev = image_pred.device
     need = L.lib().uni_postprocess_workspace_bytes(A)
@@ -154,7 +154,7 @@ def letterbox(image, input_size, swap_rb=True, device=None):
         import numpy as np
         image = torch.from_numpy(np.ascontiguousarray(image))
     if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
-        raise UnicornHipError("letterbox: needs an (h, w, 3) uint8 image")
+        raise L.UnicornHipError("letterbox: needs an (h, w, 3) uint8 image")
     if not image.is_cuda:
         image = image.to(device if device is not None else "cuda", non_blocking=True)
     image = image.contiguous()
