@@ -1,20 +1,28 @@
 #!/usr/bin/env python
-"""bench.py — frames/s of Unicorn's per-frame step on MI355X (BASELINE.json metric).
+"""bench.py - frames/s of Unicorn's per-frame step on MI355X (BASELINE.json metric).
 
-A "step" = one frame through the hot path (SURVEY.md §8d unit of work): ConvNeXt+PAFPN on the current
-frame, ref<->cur deformable interaction, 2x embedding upsample, dense HWxHW correlation + prior
-propagation (fp32), prior pyramid, unified head.  The reference-frame backbone is cached (computed once,
-external/lib/test/tracker/unicorn_sot.py:49) and is outside the timed region, as are H2D copies: frames are
-resident in HBM before timing starts.  Weights: synthetic (oracle/synth.py), data: synthetic clip.
+A "step" = NB consecutive frames of one video stream through the hot path (SURVEY.md §8d unit of work): ConvNeXt+PAFPN on
+the current frames, ref<->cur deformable interaction, 2x embedding upsample, dense HWxHW correlation + prior propagation,
+prior pyramid, unified head.  The reference-frame backbone is cached (computed once, external/lib/test/tracker/
+unicorn_sot.py:49) and is outside the timed region, as are H2D copies: frames are resident in HBM before timing starts.
+Weights: synthetic (oracle/synth.py), data: synthetic clip.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model unicorn_track_large] [--task sot]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f16x2|bf16|fp32] [--model ...] [--task sot|mot|vos]
 
-N>1: launched by torch.distributed.run, one process per GPU, one independent video stream per rank
-(streams shard one-per-GPU, no data-path collective; RCCL all_gather only for the result rows).
+HEADLINE = precision "f16x2" (fp32-equivalent split-f16 MFMA operands): the fastest mode that meets the parity bar of
+BASELINE.json:north_star (box/mask IoU >= 0.999, embedding cosine within 1e-4), checked IN THIS RUN against the CPU oracle
+("parity" key).  The bf16 mode (1 MFMA per product, misses box IoU with 8 operand bits) is reported next to it under
+"modes", the other BASELINE configs under "configs".
+
+--gpus N > 1 without a torchrun environment re-launches itself as `python -m torch.distributed.run --nproc-per-node N`:
+one process per GPU, one independent video stream per rank (streams shard one-per-GPU, no data-path
+collective; RCCL all_gather only for the result rows, external/lib/test/evaluation/running.py:111-120).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,35 +30,170 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
-import torch  # noqa: E402
 
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="unicorn_track_large")
-    ap.add_argument("--task", default="sot", choices=["sot", "mot"])
+    ap.add_argument("--task", default="sot", choices=["sot", "mot", "vos"])
+    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16", "fp32"])
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=16, help="frames of the stream processed per step (time-batched: the SOT step of a "
+                    "frame depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
     ap.add_argument("--corr-precision", type=int, default=1, choices=[0, 1],
                     help="0 = fp32 MFMA correlation, 1 = fp32-equivalent bf16x3 split (default)")
     ap.add_argument("--cpu-frames", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames of the stream processed per step (time-batched: the SOT step of a frame\n                    depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
-    ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent video streams multiplexed on one GPU (own HIP stream + context each)")
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline AND in-run parity)")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (no modes / configs sub-results)")
+    ap.add_argument("--launch-check", action="store_true", help="only rendezvous (gloo on CPU, RCCL on GPUs) and report the world size")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: one process per GPU (running.py:111-120), rendezvous on 127.0.0.1."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def box_iou_pairs(a, b):
+    import torch
+    ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+    bx1, by1, bx2, by2 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    iw = (torch.min(ax2, bx2) - torch.max(ax1, bx1)).clamp(min=0)
+    ih = (torch.min(ay2, by2) - torch.max(ay1, by1)).clamp(min=0)
+    inter = iw * ih
+    return inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
+
+
+class Stream:
+    """One video stream on one GPU: model + resident frames + the per-step closure of a task."""
+
+    def __init__(self, model_name, precision, task, H, W, NB, dev, seed, corr_prec, P=None, n_frames=4):
+        import torch
+        import synth
+        import unicorn_oracle as uo
+        from unicorn_amd.models import Unicorn
+        from unicorn_amd.ops import label_map_s8
+        self.torch, self.task, self.NB, self.dev, self.corr_prec = torch, task, NB, dev, corr_prec
+        self.cfg = uo.CONFIGS[model_name]
+        self.P = P if P is not None else synth.synth_state_dict(self.cfg)
+        self.model = Unicorn(model_name, precision=precision).cuda(dev.index)
+        self.model.load_state_dict(self.P)
+        fr, self.box = synth.synth_clip(H, W, n_frames + 1, seed=seed)
+        self.frames = [f.to(dev) for f in fr]
+        self.H, self.W = H, W
+        self.batches = [torch.cat([self.frames[1 + (k + t) % n_frames] for t in range(NB)], 0) for k in range(n_frames)]
+        with torch.no_grad():
+            _, self.d_pre = self.model(imgs=self.frames[0], mode="backbone")              # reference frame: once, untimed
+        self.lbs = label_map_s8(self.box, H, W, dev)
+        self.results = torch.zeros((4096, 8), device=dev)
+        if task == "vos":
+            from unicorn_amd.tracker import UnicornVOSTrack
+            self.trk = UnicornVOSTrack(self.model, input_size=(H, W), d_rate=self.cfg.d_rate)
+            b = self.box
+            boxes = {"1": b, "2": torch.tensor([W * 0.55, H * 0.1, W * 0.9, H * 0.45]), "3": torch.tensor([W * 0.1, H * 0.55, W * 0.4, H * 0.95])}
+            self.vos_boxes = boxes
+            self.trk.initialize(self.frames[0], {"init_object_ids": list(boxes), "init_bbox": {
+                k: [float(v[0]), float(v[1]), float(v[2] - v[0]), float(v[3] - v[1])] for k, v in boxes.items()}})
+        torch.cuda.synchronize()
+
+    def frames_per_step(self):
+        return 1 if self.task == "vos" else self.NB
+
+    def sot_batch(self, img):
+        """unicorn_sot.py:78-108 for a batch of current frames against the cached reference frame"""
+        from unicorn_amd.ops import corr_softmax_pv, prior_pyramid
+        torch, m = self.torch, self.model
+        B = img.shape[0]
+        fpn, d_cur = m(imgs=img, mode="backbone")
+        f_pre, f_cur = m(seq_dict0=self.d_pre, seq_dict1=d_cur, mode="interaction")
+        e_pre = m(feat=f_pre, mode="upsample")
+        e_cur = m(feat=f_cur, mode="upsample")
+        pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), self.lbs, precision=self.corr_prec) for b in range(B)], 0)
+        coarse = pred.view(1, B, d_cur["h"] * 2, d_cur["w"] * 2)
+        pri = tuple(t.transpose(0, 1).contiguous() for t in prior_pyramid(coarse))
+        out = m.head(fpn, pri, mode="sot")
+        return dict(fpn=fpn, e_pre=e_pre, e_cur=e_cur, coarse=coarse, head=out)
+
+    def step(self, i):
+        torch, m = self.torch, self.model
+        with torch.no_grad():
+            if self.task == "sot":
+                r = self.sot_batch(self.batches[i % len(self.batches)])
+                out = r["head"][0] if self.cfg.mask else r["head"]
+                best = torch.argmax(out[:, :, 4] * out[:, :, 5], 1)       # result row stand-in (NMS top-1 stays on device, no sync)
+                self.results[i % 4096, :6] = out[0, best[0], :6]
+            elif self.task == "mot":      # evaluate_omni-style step (mot_evaluator.py:991-1034)
+                from unicorn_amd.ops import sample_embeddings
+                img = self.batches[i % len(self.batches)]
+                out, d_cur = m(img)
+                out = out[0] if self.cfg.mask else out
+                f_pre, f_cur = m(seq_dict0=self.d_pre, seq_dict1=d_cur, mode="interaction")
+                e_cur = m(feat=f_cur, mode="upsample")
+                for bi in range(img.shape[0]):
+                    sc = out[bi, :, 4] * out[bi, :, 5:].max(1)[0]
+                    top = torch.topk(sc, 64)[1]
+                    b = out[bi, top, :4]
+                    boxes = torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
+                    emb = sample_embeddings(e_cur[bi:bi + 1], boxes)
+                    self.results[i % 4096, :4] = boxes[0]
+                    self.results[i % 4096, 4] = emb.sum()
+            else:                         # VOS: K = 3 objects, head per object, CondInst masks + postprocess (unicorn_vos.py:71-200)
+                res, _ = self.trk.step(self.frames[1 + i % (len(self.frames) - 1)])
+                d = res["1"][0]
+                if d is not None:
+                    self.results[i % 4096, :7] = d
+
+
+def timed(streams, steps, warmup, barrier):
+    for i in range(warmup):
+        for s in streams:
+            s.step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        for s in streams:
+            s.step(warmup + i)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        backend = "nccl" if torch.cuda.is_available() else "gloo"                        # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+    if args.launch_check:
+        n = torch.ones(1, device="cuda:%d" % local_rank if torch.cuda.is_available() else "cpu")
+        if dist is not None:
+            dist.all_reduce(n)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": int(n.item()), "backend": "none" if dist is None else dist.get_backend()}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the measured path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -58,139 +201,69 @@ def main():
     import synth
     import unicorn_oracle as uo
     from unicorn_amd import _lib as L
-    from unicorn_amd.models import Unicorn
-    from unicorn_amd.ops import corr_softmax_pv, label_map_s8, prior_pyramid, sample_embeddings
 
-    H, W = args.height, args.width
-    CORR_PREC = args.corr_precision
-    cfg = uo.CONFIGS[args.model]
-    P = synth.synth_state_dict(cfg)
-    S = max(1, args.streams_per_gpu)
-    models = []
-    for _ in range(S):
-        mdl = Unicorn(args.model).cuda(local_rank)
-        mdl.load_state_dict(P)
-        models.append(mdl)
-    model = models[0]
-    hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]
-    # one independent synthetic stream per (rank, slot), frames resident in HBM
-    n_frames = 4
-    clips = []
-    for j in range(S):
-        fr, bx = synth.synth_clip(H, W, n_frames + 1, seed=1 + rank * S + j)
-        clips.append(([f.to(dev) for f in fr], bx))
-    frames, box = clips[0]
-    state = []
-    with torch.no_grad():
-        for j in range(S):
-            _, dp = models[j](imgs=clips[j][0][0], mode="backbone")          # reference frame: once, untimed
-            state.append((dp, label_map_s8(clips[j][1], H, W, dev)))
-    torch.cuda.synchronize()
-    d_pre, lbs = state[0]
-    results = torch.zeros((args.steps + args.warmup, 8), device=dev)
-
-    def step(i):
-        if S == 1:
-            return step_one(i, 0)
-        j = i % S
-        with torch.cuda.stream(hip_streams[j]):
-            step_one(i, j)
-
-    NB = max(1, args.batch)
-    batches = [[torch.cat([clips[j][0][1 + (k + t) % n_frames] for t in range(NB)], 0) for k in range(n_frames)] for j in range(S)]
-
-    def step_one(i, j):
-        model = models[j]
-        d_pre, lbs = state[j]
-        img = batches[j][(i // S) % n_frames]                    # (NB,3,H,W): NB consecutive frames of the stream
-        with torch.no_grad():
-            if args.task == "sot":
-                fpn, d_cur = model(imgs=img, mode="backbone")
-                f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
-                e_pre = model(feat=f_pre, mode="upsample")
-                e_cur = model(feat=f_cur, mode="upsample")
-                pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), lbs, precision=CORR_PREC) for b in range(NB)], 0)
-                pri = prior_pyramid(pred.view(1, NB, d_cur["h"] * 2, d_cur["w"] * 2))
-                pri = tuple(t.transpose(0, 1).contiguous() for t in pri)
-                out = model.head(fpn, pri, mode="sot")
-                out = out[0] if cfg.mask else out
-                # result rows = best-scoring anchor per frame (stand-in for NMS top-1; stays on device, no sync)
-                best = torch.argmax(out[:, :, 4] * out[:, :, 5], 1)
-                results[i, :6] = out[0, best[0], :6]
-            else:   # evaluate_omni-style MOT step (mot_evaluator.py:991-1034)
-                out, d_cur = model(img)
-                out = out[0] if cfg.mask else out
-                f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
-                e_cur = model(feat=f_cur, mode="upsample")
-                for bi in range(NB):
-                    sc = out[bi, :, 4] * out[bi, :, 5:].max(1)[0]
-                    top = torch.topk(sc, 64)[1]
-                    b = out[bi, top, :4]
-                    boxes = torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
-                    emb = sample_embeddings(e_cur[bi:bi + 1], boxes)
-                    results[i, :4] = boxes[0]
-                    results[i, 4] = emb.sum()
+    H, W, NB = args.height, args.width, max(1, args.batch)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    main_s = Stream(args.model, args.precision, args.task, H, W, NB, dev, seed=1 + rank, corr_prec=args.corr_precision)
+    dt = timed([main_s], args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # result gather (fixed-stride rows over RCCL), outside the timed region like the reference's end-of-eval gather
         from unicorn_amd.parallel import gather_result_rows
-        rows = results.clone()
+        rows = main_s.results[:args.steps].clone()
         rows[:, 0] = rank
         rows[:, 1] = torch.arange(rows.shape[0], device=dev)
         table = gather_result_rows(rows)
         assert table.shape[0] == world * rows.shape[0]
-    fps = world * args.steps * NB / dt
+    fps = world * args.steps * main_s.frames_per_step() / dt
 
     # ---------------- roofline leg: per-kernel-class HIP-event timing on the launch stream (rank 0) ----------------
-    roof = None
-    extra = {}
+    roof, extra = None, {}
     if rank == 0:
         import ctypes as C
+        model = main_s.model
         prof_steps = 3
         buf = (C.c_double * 16)()
         L.check(L.lib().uni_prof_begin(model._ctx), "prof_begin")
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for i in range(prof_steps):
-            step(i)
+            main_s.step(i)
         L.check(L.lib().uni_prof_end(model._ctx, buf), "prof_end")
         v = list(buf)
         names = ["gemm", "dwconv7_ln", "gn_apply", "layernorm", "misc"]
-        pf = prof_steps * NB     # per frame
-        cls = {n: dict(ms=v[3 * i] / pf, work=v[3 * i + 1] / pf, launches=v[3 * i + 2] / prof_steps)
-               for i, n in enumerate(names)}
+        pf = prof_steps * main_s.frames_per_step()
+        cls = {n: dict(ms=v[3 * i] / pf, work=v[3 * i + 1] / pf, launches=v[3 * i + 2] / prof_steps) for i, n in enumerate(names)}
         g = cls["gemm"]
         g["bytes"] = v[15] / prof_steps
-        g["ms_step"], g["work_step"] = g["ms"] * NB, g["work"] * NB
-        peak = 2500.0   # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
+        nf = main_s.frames_per_step()
+        peak = 2500.0   # dense 16-bit MFMA TFLOP/s (MI355X_MICROARCH.md); the exact-fp32 MFMA mode is priced at 157.3
+        if args.precision == "fp32":
+            peak = 157.3
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        mfma_per_product = {"bf16": 1, "f16x2": 3, "fp32": 1}[args.precision]
         traffic, tsrc = None, None
         try:    # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
-            tsrc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_hbm_traffic.json"))[-1]
-            t = json.load(open(os.path.join(ROOT, "profiles", tsrc)))["gemm_bf16_kernel"]
+            want = "_%s_pmc_hbm_traffic.json" % args.precision
+            tsrc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(want))[-1]
+            tj = json.load(open(os.path.join(ROOT, "profiles", tsrc)))
+            t = tj.get("gemm_h2_kernel" if args.precision == "f16x2" else "gemm_bf16_kernel") or tj["gemm"]
             traffic = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
         except Exception:
-            pass
-        roof = {"kernel": "gemm_bf16_kernel (all instantiations)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+            tsrc = None
+        kname = {"bf16": "gemm_bf16_kernel / gemm_bf16_p44_kernel", "f16x2": "gemm_h2_kernel", "fp32": "gemm_f32_kernel"}[args.precision]
+        roof = {"kernel": kname + " (all instantiations)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["launches"], 1)) if "bytes" in g else None,
-                "avg_launch_us": round(1e3 * g["ms_step"] / max(g["launches"], 1), 2), "launches_per_step": g["launches"],
-                "flops_per_frame": g["work"], "flops_per_launch": round(g["work_step"] / max(g["launches"], 1))}
+                "mfma_per_product": mfma_per_product, "mfma_issue_TFLOPs": round(ach * mfma_per_product, 1),
+                "mfma_pipe_frac": round(ach * mfma_per_product / peak, 4),
+                "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["launches"], 1)),
+                "avg_launch_us": round(1e3 * g["ms"] * nf / max(g["launches"], 1), 2), "launches_per_step": g["launches"],
+                "flops_per_frame": g["work"], "flops_per_launch": round(g["work"] * nf / max(g["launches"], 1))}
         for n in ("dwconv7_ln", "gn_apply", "layernorm"):
             c_ = cls[n]
             extra[n] = {"ms_per_frame": round(c_["ms"], 4), "GBps": round(c_["work"] / (c_["ms"] * 1e-3) / 1e9, 1) if c_["ms"] > 0 else 0,
@@ -198,55 +271,144 @@ def main():
         extra["gemm_ms_per_frame"] = round(g["ms"], 4)
         extra["misc_ms_per_frame"] = round(cls["misc"]["ms"], 4)
         if args.task == "sot":   # correlation kernel alone (torch events on the current stream == launch stream)
+            from unicorn_amd.ops import corr_softmax_pv
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             with torch.no_grad():
-                fpn, d_cur = model(imgs=frames[1], mode="backbone")
-                f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
-                e_pre, e_cur = model(feat=f_pre, mode="upsample"), model(feat=f_cur, mode="upsample")
-                a, b = e_pre[0].flatten(-2), e_cur[0].flatten(-2)
-                corr_softmax_pv(a, b, lbs, precision=CORR_PREC)
+                r = main_s.sot_batch(main_s.frames[1])
+                a, b = r["e_pre"][0].flatten(-2), r["e_cur"][0].flatten(-2)
+                corr_softmax_pv(a, b, main_s.lbs, precision=args.corr_precision)
                 ev[0].record()
                 for _ in range(5):
-                    corr_softmax_pv(a, b, lbs, precision=CORR_PREC)
+                    corr_softmax_pv(a, b, main_s.lbs, precision=args.corr_precision)
                 ev[1].record()
                 torch.cuda.synchronize()
             ms = ev[0].elapsed_time(ev[1]) / 5
             n = a.shape[1]
             # precision 1 issues 6 bf16 MFMA terms per fp32-equivalent product: effective peak = 2500 / 6 TFLOP/s
             extra["corr_fp32"] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * n * n * 128 / (ms * 1e-3) / 1e12, 2),
-                                  "peak_effective": 157.3 if CORR_PREC == 0 else round(2500.0 / 6, 1),
-                                  "mode": "fp32 MFMA" if CORR_PREC == 0 else "bf16x3 split (6 exact partial products, fp32 accumulate)"}
+                                  "peak_effective": 157.3 if args.corr_precision == 0 else round(2500.0 / 6, 1),
+                                  "mode": "fp32 MFMA" if args.corr_precision == 0 else "bf16x3 split (6 exact partial products, fp32 accumulate)"}
 
-    # ---------------- CPU baseline: the oracle (port of the reference) on the host cores, bounded sample ----------------
-    cpu = None
+    # ---------------- CPU baseline (the oracle = port of the reference, host cores, bounded sample) + in-run parity ----------------
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        cores = min(cores, 16)
+        cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)
-        cf, cbox = synth.synth_clip(H, W, 1 + args.cpu_frames, seed=1)
+        P, cfg = main_s.P, main_s.cfg
+        cf = [f.cpu() for f in main_s.frames[:1 + args.cpu_frames]]
+        ious, coss, prs = [], [], []
         with torch.no_grad():
-            st = uo.sot_init(P, cfg, cf[0], cbox)
-            t1 = time.perf_counter()
+            st = uo.sot_init(P, cfg, cf[0], main_s.box)
+            cdt = 0.0
             for i in range(args.cpu_frames):
-                if args.task == "sot":
-                    uo.sot_step(P, cfg, st, cf[1 + i])
+                t1 = time.perf_counter()
+                if args.task == "mot":
+                    o_out, _, _ = uo.mot_whole(P, cfg, cf[1 + i])
+                    o = None
                 else:
-                    uo.mot_whole(P, cfg, cf[1 + i])
-            cdt = time.perf_counter() - t1
+                    o = uo.sot_step(P, cfg, st, cf[1 + i])
+                cdt += time.perf_counter() - t1
+                if args.task == "sot":     # parity of the TIMED configuration (same model object, same precision, same frames)
+                    r = main_s.sot_batch(main_s.frames[1 + i])
+                    ho = o["head"][0] if cfg.mask else o["head"]
+                    hh = (r["head"][0] if cfg.mask else r["head"]).cpu()
+                    score = ho[0, :, 4] * ho[0, :, 5]
+                    top = torch.argsort(score, descending=True)[:500]
+                    ious.append(box_iou_pairs(hh[0, top, :4], ho[0, top, :4]))
+                    ea, eb = r["e_cur"].cpu().flatten(2)[0].double(), o["embed_cur"].flatten(2)[0].double()
+                    coss.append((ea * eb).sum(0) / (ea.norm(dim=0) * eb.norm(dim=0)).clamp_min(1e-30))
+                    prs.append(float((r["coarse"].cpu().reshape(-1) - o["coarse"].reshape(-1)).abs().max()))
         cpu = {"value": round(args.cpu_frames / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames of the same %s %s step at %dx%d, fp32, torch CPU (oracle/unicorn_oracle.py)"
                          % (args.cpu_frames, args.model, args.task, H, W)}
+        if ious:
+            iou = torch.cat(ious)
+            parity = {"vs": "CPU oracle (fp32), %d frames of the timed stream, top-500 anchors by oracle score" % args.cpu_frames,
+                      "precision": args.precision, "box_iou_min": round(float(iou.min()), 6), "box_iou_mean": round(float(iou.mean()), 6),
+                      "embed_cos_min": round(float(torch.cat(coss).min()), 8), "prior_max_abs": max(prs), "mask_iou_min": None,
+                      "bar": "box/mask IoU >= 0.999, embedding cosine within 1e-4 (BASELINE.json north_star)",
+                      "pass": bool(iou.min() >= 0.999 and torch.cat(coss).min() >= 1 - 1e-4)}
+
+    # ---------------- sub-results: other precision modes, single-frame latency, the other BASELINE configs ----------------
+    modes, configs = {}, {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        def quick(model_name, precision, task, nb, steps=4, warmup=1, P=None, keep=False):
+            s = Stream(model_name, precision, task, H, W, nb, dev, seed=1, corr_prec=args.corr_precision, P=P)
+            d = timed([s], steps, warmup, barrier)
+            f = steps * s.frames_per_step() / d
+            r = {"fps": round(f, 2), "ms_per_frame": round(1e3 / f, 4), "frames_per_step": s.frames_per_step(), "precision": precision}
+            if not keep:      # one extra context (weights + workspace) alive at a time
+                del s
+                s = None
+                torch.cuda.empty_cache()
+            return s, r
+        Pm = main_s.P
+        for prec in ("bf16", "f16x2"):
+            if prec == args.precision:
+                modes[prec] = {"fps": round(fps, 2), "ms_per_frame": round(1e3 / fps, 4), "frames_per_step": main_s.frames_per_step(), "precision": prec}
+            else:
+                _, modes[prec] = quick(args.model, prec, args.task, NB, P=Pm)
+        modes["bf16"]["parity_note"] = "bf16 operands miss the box-IoU bar with synthetic weights (min ~0.56, profiles/r02_precision_budget.json)"
+        # single-frame latency of the headline mode: one frame per step, synchronised every frame (the reference's own call pattern)
+        with torch.no_grad():
+            for _ in range(2):
+                main_s.sot_batch(main_s.frames[1]) if args.task == "sot" else main_s.step(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nrep = 10
+            for i in range(nrep):
+                if args.task == "sot":
+                    main_s.sot_batch(main_s.frames[1 + i % 4])
+                else:
+                    main_s.step(i)
+                torch.cuda.synchronize()
+            lat = (time.perf_counter() - t1) / nrep
+        if args.task == "sot":
+            configs["single_frame_latency"] = {"ms": round(1e3 * lat, 3), "fps": round(1.0 / lat, 2), "frames_per_step": 1, "precision": args.precision,
+                                               "note": "one (1,3,%d,%d) frame per call, host-synchronised per frame" % (H, W)}
+        torch.cuda.empty_cache()
+        # BASELINE.json configs[1..3]
+        _, configs["tiny_sot"] = quick("unicorn_track_tiny", args.precision, "sot", NB)
+        _, configs["tiny_sot_bf16"] = quick("unicorn_track_tiny", "bf16", "sot", NB)
+        _, configs["large_mot_challenge_step"] = quick("unicorn_track_large_mot_challenge", args.precision, "mot", NB)
+        vs, configs["large_vos_k3"] = quick("unicorn_track_large_mask", args.precision, "vos", 1, steps=6, warmup=2, keep=True)
+        configs["large_vos_k3"]["note"] = "3 objects per frame: one backbone, per object correlation + head + CondInst masks + postprocess (UnicornVOSTrack.step)"
+        if not args.no_cpu_baseline:      # mask parity of the VOS config on one frame (oracle loop over the 3 objects)
+            with torch.no_grad():
+                res, _ = vs.trk.step(vs.frames[1])
+                torch.set_num_threads(min(os.cpu_count() or 1, 16))
+                st = uo.vos_init(vs.P, vs.cfg, vs.frames[0].cpu(), vs.vos_boxes)
+                exp = uo.vos_step(vs.P, vs.cfg, st, vs.frames[1].cpu())
+            mi, bi = [], []
+            for k in vs.vos_boxes:
+                d_o, m_o = exp[k]
+                d_h, m_h = res[k]
+                if d_o is None or d_h is None:
+                    continue
+                a, b = m_h.cpu() > 0.5, m_o > 0.5
+                mi.append(float((a & b).sum()) / max(float((a | b).sum()), 1.0))
+                cx = lambda t: torch.stack([(t[0] + t[2]) / 2, (t[1] + t[3]) / 2, t[2] - t[0], t[3] - t[1]])[None]
+                bi.append(float(box_iou_pairs(cx(d_h.cpu()), cx(d_o))[0]))
+            if mi and parity is not None:
+                parity["mask_iou_min"] = round(min(mi), 6)
+                parity["vos_best_box_iou_min"] = round(min(bi), 6)
+                parity["pass"] = bool(parity["pass"] and min(mi) >= 0.999)
+            configs["large_vos_k3"]["parity"] = {"mask_iou_min": min(mi) if mi else None, "best_box_iou_min": min(bi) if bi else None}
 
     if rank == 0:
+        nf = main_s.frames_per_step()
+        dtype = {"f16x2": "f16x2 (fp32-equivalent: split-f16 MFMA operands, fp32 accumulate)", "bf16": "bf16", "fp32": "f32"}[args.precision]
         line = {
-            "metric": "frames/sec @ 800x1280 %s" % args.model, "value": round(fps, 3), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "frames_per_step": NB, "ms_per_frame": round(1e3 * dt / (args.steps * NB), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
-            "config": {"workload": "%s %s per-frame step %dx%d (backbone+FPN, deform interaction, embedding, fp32 correlation, "
-                                   "head); one independent stream per GPU, %d consecutive frames per step" % (args.model, args.task.upper(), H, W, NB),
-                       "model": args.model, "task": args.task, "frames_per_step": NB, "streams": world * S, "streams_per_gpu": S, "weights": "synthetic (oracle/synth.py)",
-                       "corr_dtype": "f32" if CORR_PREC == 0 else "f32-equivalent (bf16x3 split operands, fp32 accumulate)", "accum": "f32"},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": extra,
+            "metric": "frames/sec @ %dx%d %s" % (H, W, args.model), "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "frames_per_step": nf, "ms_per_frame": round(1e3 * dt / (args.steps * nf), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "%s %s per-frame step %dx%d (backbone+FPN, deform interaction, embedding, fp32-equivalent correlation, "
+                                   "head); one independent stream per GPU, %d consecutive frames per step" % (args.model, args.task.upper(), H, W, nf),
+                       "model": args.model, "task": args.task, "precision": args.precision, "frames_per_step": nf, "streams": world,
+                       "weights": "synthetic (oracle/synth.py)",
+                       "corr_dtype": "f32" if args.corr_precision == 0 else "f32-equivalent (bf16x3 split operands, fp32 accumulate)", "accum": "f32"},
+            "parity": parity, "roofline": roof, "cpu_baseline": cpu, "modes": modes, "configs": configs, "kernels": extra,
         }
         print(json.dumps(line))
     if dist is not None:
