@@ -1,8 +1,9 @@
 """End-to-end parity of the HIP path (through unicorn_amd's reference-shaped Python API -> C-ABI) against
 (a) golden vectors produced by the REAL reference (tiny, 320x320) and (b) the CPU oracle at 800x1280.
 
-Two precision modes of the same kernels are tested (DESIGN.md "precision"):
-  precision="fp32"  exact-fp32 MFMA everywhere: must meet the north_star bar
+Three precision modes of the same kernels are tested (DESIGN.md "precision"):
+  precision="f16x2" fp32-equivalent split-f16 MFMA operands (the bench headline) and
+  precision="fp32"  exact-fp32 MFMA everywhere: both must meet the north_star bar
         box IoU >= 0.999, mask IoU >= 0.999, embedding cosine within 1e-4 (min over pixels >= 1 - 1e-4),
         feature maps rel-L2 <= 1e-4, propagated prior max-abs <= 1e-4
   precision="bf16"  benchmark configuration (bf16 MFMA operands, fp32 accumulate / residual / statistics, fp32
@@ -142,14 +143,26 @@ def test_tiny_320_vs_reference_golden(exp, precision, golden_dir):
         assert met["box_iou_mean_top200"] > 0.75, met
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_sot(exp, H, W, P, cfg, frames, box):
+    """the CPU oracle costs seconds per frame on the large model: one evaluation per (exp, size) for all precisions"""
+    key = (exp, H, W)
+    if key not in _ORACLE_CACHE:
+        torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box has 100s of cores; torch CPU ops scale badly past ~16
+        with torch.no_grad():
+            st = uo.sot_init(P, cfg, frames[0], box)
+            _ORACLE_CACHE[key] = (st, uo.sot_step(P, cfg, st, frames[1]))
+    return _ORACLE_CACHE[key]
+
+
 def _vs_oracle(exp, H, W, tag, precision="bf16"):
     m, cfg, P = build(exp, precision)
     frames, box = synth.synth_clip(H, W, 2, seed=1)
     r = hip_sot_step(m, cfg, frames, box)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box has 100s of cores; torch CPU ops scale badly past ~16
-    with torch.no_grad():
-        st = uo.sot_init(P, cfg, frames[0], box)
-        o = uo.sot_step(P, cfg, st, frames[1])
+    del m
+    st, o = _oracle_sot(exp, H, W, P, cfg, frames, box)
     met = {}
     assert torch.equal(r["lbs"].cpu(), st["lbs_pre"])
     for i in range(3):
@@ -194,7 +207,7 @@ def _vs_oracle(exp, H, W, tag, precision="bf16"):
             mo = uo.aligned_bilinear(uo.dynamic_mask_head(cfg, o["head"][4], o["head"][2][0][idx], o["head"][1][idx],
                                                           o["head"][3][0][idx], o["head"][5]), cfg.d_rate)
             mh = condinst_masks(r["head"][4], r["head"][5], r["head"][2][0][idx.cuda()], r["head"][1][idx.cuda()],
-                                r["head"][3][0][idx], m.up_rate, cfg.d_rate).cpu()
+                                r["head"][3][0][idx], cfg.up_rate, cfg.d_rate).cpu()
             a, b = mh > 0.5, mo > 0.5
             inter = (a & b).flatten(1).sum(1).float()
             union = (a | b).flatten(1).sum(1).float().clamp_min(1)
@@ -232,6 +245,115 @@ def test_tiny_sot_800x1280_vs_oracle(precision):
 def test_tiny_mask_ragged_size_vs_oracle(precision):
     """VOS-style head (CondInst) at a non-square size that is ragged for every tile/strip/split: 352x608."""
     _assert_bar(_vs_oracle("unicorn_track_tiny_mask", 352, 608, "tiny_mask_352x608_" + precision, precision), precision)
+
+
+# ------------------------------------------------------------------------------------------------
+# the LARGE models at 800x1280: the configurations bench.py times (BASELINE.json configs[2..3] + the headline)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_large_sot_800x1280_vs_oracle(precision):
+    """unicorn_track_large SOT step, the bench headline workload: depth-27 stage, C = 1536 tiles, the 256x256 GEMM tiles on
+    their real shapes.  f16x2 (the headline precision) must meet the north_star bar; bf16 is held to its documented error
+    class (embedding cosine within 1e-4 holds, box IoU does not: profiles/r02_precision_budget.json)."""
+    _assert_bar(_vs_oracle("unicorn_track_large", 800, 1280, "large_sot_800x1280_" + precision, precision), precision)
+
+
+def test_large_mask_sot_and_condinst_800x1280_vs_oracle():
+    """unicorn_track_large_mask: head + controllers + mask branch + CondInst masks of the kept detections (config 3's head)."""
+    met = _vs_oracle("unicorn_track_large_mask", 800, 1280, "large_mask_800x1280_f16x2", "f16x2")
+    _assert_bar(met, "f16x2")
+    assert "mask_iou_min" in met and max(met["dyn_params"], met["mask_feats"], met["up_masks"]) < 1e-4, met
+
+
+def test_large_mot_challenge_evaluate_omni_sequence():
+    """BASELINE.json configs[2]: the per-frame sequence of evaluate_omni (unicorn/evaluators/mot_evaluator.py:991-1045) on
+    unicorn_track_large_mot_challenge (num_classes = 1): mode="whole" -> postprocess -> interaction(prev, cur) -> ONE upsample ->
+    instance embeddings at the box centres -> QuasiDense match, HIP path (f16x2) vs the oracle on 2 frames.  With synthetic
+    weights obj*cls ~ 1e-4, so the confidence threshold is set from the oracle's score distribution (same value both sides)."""
+    import copy
+    import assoc_oracle as ao
+    from unicorn_amd.ops import sample_embeddings
+    from unicorn_amd.tracker import QuasiDenseEmbedTracker
+    from unicorn_amd.utils.boxes import postprocess
+    exp, H, W = "unicorn_track_large_mot_challenge", 800, 1280
+    m, cfg, P = build(exp, "f16x2")
+    frames, _ = synth.synth_clip(H, W, 3, seed=5)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    kw = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+              memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+              match_metric="bisoftmax")
+    trk_h, st_o = QuasiDenseEmbedTracker(**kw), ao.QDState(**kw)
+    pre_h = pre_o = None
+    thr = None
+    met = {"box_iou_min": 1.0, "embed_cos_min": 1.0}
+    for fid in (1, 2):
+        with torch.no_grad():
+            out_o, d_o, _ = uo.mot_whole(P, cfg, frames[fid])
+            out_h, d_h = m(frames[fid].cuda())
+        assert out_h.shape == out_o.shape == (1, 21000, 6)
+        if thr is None:
+            sc = (out_o[0, :, 4] * out_o[0, :, 5]).sort(descending=True)[0]
+            thr = float((sc[199] + sc[200]) / 2)                        # ~200 candidates before NMS
+        det_o = uo.postprocess(out_o.clone(), 1, thr, 0.7)[0]
+        det_h = postprocess(out_h.clone(), 1, thr, 0.7)[0]
+        assert det_o is not None and det_h is not None and det_h.shape == det_o.shape, (det_h is None, det_o is None)
+        cx = lambda t: torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], 1)
+        iou = box_iou_pairs(cx(det_h[:, :4].cpu()), cx(det_o[:, :4]))
+        met["box_iou_min"] = min(met["box_iou_min"], float(iou.min()))
+        assert iou.min() > 0.999, iou.min()                              # same detections, same order
+        with torch.no_grad():
+            if fid == 1:
+                pre_h, pre_o = copy.deepcopy(d_h), copy.deepcopy(d_o)    # mot_evaluator.py:1014-1015
+            _, f_h = m(seq_dict0=pre_h, seq_dict1=d_h, mode="interaction")
+            e_h = m(feat=f_h, mode="upsample")
+            _, f_o = uo.forward_interaction(P, pre_o, d_o)
+            e_o = uo.forward_upsample(P, f_o)
+            pre_h, pre_o = copy.deepcopy(d_h), copy.deepcopy(d_o)
+            emb_o = uo.sample_instance_embeddings(e_o, det_o[:, :4])
+            emb_h = sample_embeddings(e_h, det_h[:, :4].contiguous()).cpu()
+        cos = torch.nn.functional.cosine_similarity(emb_h.double(), emb_o.double(), dim=1)
+        met["embed_cos_min"] = min(met["embed_cos_min"], float(cos.min()))
+        assert cos.min() > 1 - 1e-4, cos.min()
+        labels = torch.ones((det_o.shape[0],))
+        tin_o = torch.cat((det_o[:, :4], det_o[:, 4:5] * det_o[:, 5:6]), 1)
+        tin_h = torch.cat((det_h[:, :4], det_h[:, 4:5] * det_h[:, 5:6]), 1).cpu()
+        b_h, _, ids_h = trk_h.match(tin_h, labels, emb_h, fid)
+        b_o, _, ids_o, _ = ao.qd_match(st_o, tin_o, labels, emb_o, fid)
+        assert torch.equal(torch.as_tensor(ids_h).long(), torch.as_tensor(ids_o).long()), (ids_h, ids_o)
+    METRICS["large_mot_challenge_omni_f16x2"] = met
+    _dump()
+
+
+def test_large_mask_vos_k3_tracker_step_vs_oracle():
+    """BASELINE.json configs[3]: unicorn_track_large_mask VOS step with K = 3 objects (UnicornVOSTrack: correlation, head,
+    postprocess_inst, CondInst mask of the best instance) vs the oracle's per-object loop, f16x2."""
+    from unicorn_amd.tracker import UnicornVOSTrack
+    m, cfg, P = build("unicorn_track_large_mask", "f16x2")
+    H, W = 800, 1280
+    frames, box = synth.synth_clip(H, W, 2, seed=3)
+    boxes = {"1": box, "2": torch.tensor([W * 0.55, H * 0.1, W * 0.9, H * 0.45]), "3": torch.tensor([W * 0.1, H * 0.55, W * 0.4, H * 0.95])}
+    trk = UnicornVOSTrack(m, input_size=(H, W), d_rate=cfg.d_rate)
+    trk.initialize(frames[0].cuda(), {"init_object_ids": list(boxes), "init_bbox": {k: [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])]
+                                                                                    for k, b in boxes.items()}})
+    res, _ = trk.step(frames[1].cuda())
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        st = uo.vos_init(P, cfg, frames[0], boxes)
+        exp = uo.vos_step(P, cfg, st, frames[1])
+    met = {"mask_iou_min": 1.0, "box_iou_min": 1.0}
+    for k in boxes:
+        d_o, m_o = exp[k]
+        d_h, m_h = res[k]
+        assert (d_o is None) == (d_h is None), k
+        if d_o is None:
+            continue
+        cx = lambda t: torch.stack([(t[0] + t[2]) / 2, (t[1] + t[3]) / 2, t[2] - t[0], t[3] - t[1]])[None]
+        met["box_iou_min"] = min(met["box_iou_min"], float(box_iou_pairs(cx(d_h.cpu()), cx(d_o))[0]))
+        a, b = m_h.cpu() > 0.5, m_o > 0.5
+        met["mask_iou_min"] = min(met["mask_iou_min"], float((a & b).sum()) / max(float((a | b).sum()), 1.0))
+    METRICS["large_mask_vos_k3_f16x2"] = met
+    _dump()
+    assert met["box_iou_min"] > 0.999 and met["mask_iou_min"] > 0.999, met
 
 
 def test_whole_mot_mode_matches_head_with_zero_priors():
