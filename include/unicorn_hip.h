@@ -58,7 +58,8 @@ typedef struct uni_model_cfg {
     int32_t embed_dim;   /* 128 */
     int32_t up_rate;     /* 8 // d_rate (4) */
     int32_t d_rate;      /* 2 */
-    int32_t precision;   /* 0 = bf16 MFMA operands / fp32 accumulate (default); 1 = exact fp32 (v_mfma_f32_32x32x2_f32) */
+    int32_t precision;   /* operand format of every dense contraction (fp32 accumulate): 0 = bf16; 1 = exact fp32
+                            (v_mfma_f32_32x32x2_f32); 2 = "f16x2" split f16, fp32-equivalent (3 f16 MFMAs per product) */
 } uni_model_cfg;
 
 const char* uni_last_error(void);
@@ -97,7 +98,9 @@ int uni_interaction(uni_ctx* ctx, const float* feat_ref, const float* pos_ref, c
 /* feat: NHWC fp32 (B,h,w,256) -> embed: NHWC fp32 (B,2h,2w,embed_dim). */
 int uni_upsample(uni_ctx* ctx, const float* feat, int B, int h, int w, float* embed, uni_stream_t stream);
 /* fpn*: as produced by uni_backbone_fpn for B (H,W) images; prior*: (B,H/8*W/8), (B,H/16*W/16), (B,H/32*W/32) fp32
- * (one prior per image and level).  mode: 0 = "sot", 1 = "mot".  out: (B, A, 5+nc) fp32 decoded, A = sum of level
+ * (one prior per image and level).  mode bit 0: 0 = "sot", 1 = "mot"; bit 1 (value 2): raw rows, i.e. the reference's
+ * decode_in_inference = False (unicorn_head.py:436-439, tools/export_torchscript.py:66; not for mask models).
+ * out: (B, A, 5+nc) fp32 decoded, A = sum of level
  * sizes, nc = 1 (sot) or num_classes (mot).  Mask models additionally fill dyn_params (B,A,169), mask_feats
  * (B,H/8,W/8,8) NHWC and up_masks (B,H/8,W/8,9*up_rate^2) NHWC (pass NULL for box-only models). */
 int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,

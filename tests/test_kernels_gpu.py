@@ -97,7 +97,7 @@ def test_gemm_conv(L, cfg, case):
         assert torch.allclose(s_got, s_ref, rtol=1e-3, atol=1e-2), (s_got - s_ref).abs().max()
 
 
-@pytest.mark.parametrize("cfg", [144, 88, 44, 444, 445, 224, 0])
+@pytest.mark.parametrize("cfg", [144, 44, 444, 445, 224, 0])
 @pytest.mark.parametrize("case", [
     # (M, N, K, act, res, outF, outB): > 256 tiles of 256x128 so persistent blocks walk several tiles
     (70001, 256, 64, 2, False, False, True),      # one K step per tile (drain slices outnumber K steps), GELU, bf16 out
@@ -480,7 +480,7 @@ def test_h2_cast_and_pack_formats(L):
     assert (wd - ref).abs().max() <= ref.abs().max() * 2.0 ** -21
 
 
-@pytest.mark.parametrize("cfg", [0, 44, 22, 12, 21, 11])
+@pytest.mark.parametrize("cfg", [0, 42, 48, 44, 22, 12, 21, 11])
 @pytest.mark.parametrize("case", [
     # (Hin, Win, Cin, N, KH, stride, pad, act, bias, res, stats_G)
     (20, 24, 96, 384, 1, 1, 0, 2, True, False, 0),        # pwconv1 + GELU, K = 96 (3 steps of 32)
@@ -547,7 +547,7 @@ def test_gemm_h2_large_and_subnormal_lo(L):
     mag = x.abs().double() @ w.abs().double().cuda().t()
     A = cast_h2(L, x)
     Wp, wscale = pack_weight_h2(L, w.reshape(N, K, 1, 1))
-    for cfg in (0, 44, 22):
+    for cfg in (0, 42, 48, 44, 22):
         outF = torch.full((M, N), float("nan"), device="cuda")
         L.check(L.lib().uni_gemm_h2(L.ptr(A), K, L.ptr(Wp), wscale, M, N, M, 1, K, 1, 1, 1, 0, None, 0, None, N,
                                     L.ptr(outF), N, None, N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
@@ -563,3 +563,39 @@ def test_wrapper_error_paths_raise_unicorn_error(L):
         postprocess_image(torch.zeros(10, 6, device="cuda", dtype=torch.float64), 1, 0.1, 0.5)
     with pytest.raises(L.UnicornHipError):
         letterbox(torch.zeros(8, 8, 3, device="cuda", dtype=torch.float32), (32, 32))
+
+
+@pytest.mark.parametrize("cfg", [144, 44, 48, 0])
+@pytest.mark.parametrize("case", [
+    # (M, N, K, act, res, outF, outB): several tiles per persistent block
+    (70001, 256, 64, 2, False, False, True),      # two K steps per tile, GELU, operand-format out, ragged M
+    (35003, 512, 160, 0, True, True, True),       # residual + fp32 + operand-format out
+    (9001, 3072, 320, 2, False, False, True),     # pwconv1-like
+    (20000, 768, 1024, 0, True, True, False),     # pwconv2-like, fp32 out only
+    (5000, 136, 256, 1, False, True, True),       # N not a multiple of the tile (136 = 128 + 8), ReLU
+])
+def test_gemm_h2_persistent(L, cfg, case):
+    """gemm_h2p.hip (cfg 144) against fp64 on the unrounded operands, next to the one-tile-per-block kernels."""
+    M, N, K, act, use_res, use_F, use_B = case
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 2.0).cuda()
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    res = torch.randn(M, N, generator=g).cuda() if use_res else None
+    raw = x.double() @ w.double().cuda().t() + bias.double()
+    mag = x.abs().double() @ w.abs().double().cuda().t()
+    exp = ACTS[act](raw) + (res.double() if use_res else 0)
+    A = cast_h2(L, x)
+    Wp, wscale = pack_weight_h2(L, w.reshape(N, K, 1, 1))
+    outF = torch.full((M, N), float("nan"), device="cuda") if use_F else None
+    outB = torch.zeros((M, N), device="cuda", dtype=torch.int32) if use_B else None
+    L.check(L.lib().uni_gemm_h2(L.ptr(A), K, L.ptr(Wp), wscale, M, N, M, 1, K, 1, 1, 1, 0, L.ptr(bias), act, L.ptr(res), N,
+                                L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
+    torch.cuda.synchronize()
+    tol = mag * 2.0 ** -20 + 1e-6
+    if use_F:
+        assert torch.isfinite(outF).all()
+        assert ((outF.double() - exp).abs() <= tol * 1.2).all(), ((outF.double() - exp).abs() / tol).max()
+    if use_B:
+        dec, _, _ = h2_decode(outB, M, N)
+        assert ((dec.double() - exp).abs() <= tol * 1.2 + exp.abs() * 2.0 ** -21).all()

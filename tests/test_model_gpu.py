@@ -510,3 +510,28 @@ def test_load_state_dict_reports_missing_and_unexpected():
     frames, _ = synth.synth_clip(64, 64, 1, seed=0)
     fpn, _ = m3(imgs=frames[0].cuda(), mode="backbone")
     assert torch.isfinite(fpn[0]).all()
+
+
+def test_raw_outputs_decode_in_inference_false():
+    """tools/export_torchscript.py:66 sets model.head.decode_in_inference = False: the head then returns the undecoded rows
+    [reg(4), sigmoid(obj), sigmoid(cls)] (unicorn_head.py:430-439); head.decode_outputs on them equals the decoded output
+    (tools/track.py:208-209 `decoder`).  The mask head has no such path (unicorn_head_mask.py:470 raises ValueError)."""
+    m, cfg, P = build("unicorn_track_tiny", "f16x2")
+    frames, _ = synth.synth_clip(320, 320, 2, seed=1)
+    with torch.no_grad():
+        fpn, _ = m(imgs=frames[1].cuda(), mode="backbone")
+        pri = tuple(torch.zeros((1, 1, 320 // s, 320 // s), device="cuda") for s in (8, 16, 32))
+        dec = m.head(fpn, pri, mode="mot").clone()
+        m.head.decode_in_inference = False
+        raw = m.head(fpn, pri, mode="mot")
+        m.head.decode_in_inference = True
+        fo, _ = uo.forward_backbone(P, cfg, frames[1])
+        outs, _ = uo._head_trunk(P, cfg, fo, tuple(p.cpu() for p in pri), "mot")
+    raw_o = torch.cat([o.flatten(2) for o in outs], 2).permute(0, 2, 1)
+    assert raw.shape == raw_o.shape == (1, 2100, 13)
+    assert (raw.cpu() - raw_o).abs().max() < 2e-4
+    assert torch.allclose(m.head.decode_outputs(raw.clone()), dec, atol=1e-5, rtol=1e-6)
+    mm, _, _ = build("unicorn_track_tiny_mask", "f16x2")
+    mm.head.decode_in_inference = False
+    with pytest.raises(ValueError):
+        mm.head(fpn, pri, mode="mot")

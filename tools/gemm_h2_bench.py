@@ -1,0 +1,66 @@
+"""Micro-benchmark of the split-f16 ("f16x2") GEMM kernel (gemm_h2.hip) over the dominant shapes of the 800x1280 large model
+at GEMM_SCALE frames per launch (default 16 = the bench step).  TF = fp32-EQUIVALENT (algorithmic) TFLOP/s; the MFMA pipe
+issues 3x that.      python tools/gemm_h2_bench.py [cfg ...]      (cfg 0 = heuristic, 48 / 44 / 22 / ...)"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unicorn_amd import _lib as L
+
+lib = L.lib()
+SCALE = int(os.environ.get("GEMM_SCALE", "16"))
+SHAPES = [
+    # (name, Hin, Win, Cin, N, k, act, res, outF, outB)   act 2 = GELU
+    ("s2.pw1+gelu", 4000, 1, 768, 3072, 1, 2, 0, 0, 1), ("s2.pw2+res", 4000, 1, 3072, 768, 1, 0, 1, 1, 0),
+    ("s0.pw1+gelu", 64000, 1, 192, 768, 1, 2, 0, 0, 1), ("s0.pw2+res", 64000, 1, 768, 192, 1, 0, 1, 1, 0),
+    ("s1.pw1+gelu", 16000, 1, 384, 1536, 1, 2, 0, 0, 1), ("s1.pw2+res", 16000, 1, 1536, 384, 1, 0, 1, 1, 0),
+    ("s3.pw1+gelu", 1000, 1, 1536, 6144, 1, 2, 0, 0, 1), ("s3.pw2+res", 1000, 1, 6144, 1536, 1, 0, 1, 1, 0),
+    ("head.s8.3x3", 100, 160, 256, 256, 3, 0, 0, 1, 0), ("fpn.s16.3x3", 50, 80, 384, 384, 3, 0, 0, 1, 0),
+    ("att.pw1+gelu", 16000, 1, 256, 1024, 1, 2, 0, 0, 1), ("plain 768^2 noepi", 4000, 1, 768, 768, 1, 0, 0, 0, 1),
+    ("s2.pw1 noact outB", 4000, 1, 768, 3072, 1, 0, 0, 0, 1), ("s2.pw1 noact outF", 4000, 1, 768, 3072, 1, 0, 0, 1, 0),
+    ("s2.pw1 relu outB", 4000, 1, 768, 3072, 1, 1, 0, 0, 1),
+]
+if os.environ.get("ONLY"):
+    SHAPES = [s_ for s_ in SHAPES if os.environ["ONLY"] in s_[0]]
+ZERO = bool(os.environ.get("ZERO"))
+cfgs = [int(a) for a in sys.argv[1:]] or [0, 48, 44, 22]
+print("%-18s %8s %6s %6s | " % ("shape", "M", "N", "K") + " ".join("%12s" % ("cfg%d" % c) for c in cfgs))
+for name, Hin, Win, Cin, N, k, act, use_res, use_F, use_B in SHAPES:
+    B = SCALE
+    pad = (k - 1) // 2
+    if k == 1:
+        Hin_, Win_ = Hin * B, 1
+        M = Hin_
+    else:
+        Hin_, Win_ = Hin * B, Win          # B images stacked along H (halo rows between images are harmless for timing)
+        M = Hin_ * Win_
+    K = Cin * k * k
+    A = torch.randint(-2 ** 30, 2 ** 30, (Hin_ * Win_, Cin), device="cuda", dtype=torch.int32)
+    x = torch.randn(Hin_ * Win_, Cin, device="cuda") * (0.0 if ZERO else 1.0)
+    L.check(lib.uni_cast_h2(L.ptr(x), Cin, L.ptr(A), Cin, Hin_ * Win_, Cin, L.stream_ptr()), "cast")
+    Npad, Kpad = (N + 255) // 256 * 256, (K + 63) // 64 * 64
+    wf = torch.randn(Npad, Kpad, device="cuda") * (0.0 if ZERO else 100.0)
+    Wp = torch.empty((Npad, Kpad), device="cuda", dtype=torch.int32)
+    L.check(lib.uni_cast_h2(L.ptr(wf), Kpad, L.ptr(Wp), Kpad, Npad, Kpad, L.stream_ptr()), "cast")
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda") if use_res else None
+    outF = torch.empty((M, N), device="cuda") if use_F else None
+    outB = torch.empty((M, N), device="cuda", dtype=torch.int32) if use_B else None
+    out = []
+    for cfg in cfgs:
+        def run():
+            L.check(lib.uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), 1.0 / 128, M, N, Hin_, Win_, Cin, k, k, 1, pad, L.ptr(bias), act, L.ptr(res), N,
+                                    L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
+        for _ in range(2):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        out.append("%5.0fTF/%5.0fus" % (2.0 * M * N * K / ms / 1e9, ms * 1e3))
+    print("%-18s %8d %6d %6d | " % (name, M, N, K) + " ".join(out), flush=True)

@@ -93,6 +93,7 @@ int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fp
              const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
              uni_stream_t stream) {
     UNI_REQUIRE(ctx && fpn0 && fpn1 && fpn2 && prior8 && prior16 && prior32 && out, "head: NULL argument");
+    UNI_REQUIRE(mode >= 0 && mode <= 3, "head: mode %d (bit 0: 0 = sot / 1 = mot, bit 1: raw outputs, decode_in_inference = False)", mode);
     API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, B, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
 }
 int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream) {
@@ -207,7 +208,7 @@ int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int 
     UNI_REQUIRE(g.M == M, "gemm_h2: M=%d does not match conv geometry (%d)", M, g.M);
     g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
     g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
-    g.b32 = FMT_H2; g.wscale = wscale;
+    g.b32 = FMT_H2; g.wscale = wscale; g.dbg = force_cfg / 1000;
     API(launch_gemm(g, S(stream)));
 }
 int uni_cast_h2(const float* x, int ldx, void* out, int ldo, int M, int C, uni_stream_t stream) {

@@ -682,6 +682,8 @@ int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s) {
 int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
                 const float* prior16, const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params,
                 float* mask_feats, float* up_masks, hipStream_t s) {
+    const bool raw = (mode & 2) != 0;     // decode_in_inference = False (unicorn_head.py:436-439): [reg, sigmoid(obj), sigmoid(cls)] rows undecoded
+    mode &= 1;
     UNI_REQUIRE(mode == 0 || mode == 1, "head: mode has to be 0 ('sot') or 1 ('mot')");   // unicorn_head.py:291-292
     UNI_REQUIRE(H % 32 == 0 && W % 32 == 0, "head: H=%d W=%d", H, W);
     UNI_REQUIRE(B >= 1 && B <= 64, "head: batch %d unsupported (1..64)", B);
@@ -764,7 +766,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         }
         c->ws_off = lvl_base + 3 * slice_bytes;
     }
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, HWk[0], Wk[0], HWk[1], Wk[1], HWk[2], Wk[2], nch, s, B); }));
+    if (!raw) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, HWk[0], Wk[0], HWk[1], Wk[1], HWk[2], Wk[2], nch, s, B); }));
     if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162
         const int M8 = B * HWk[0];
         float* xm = wsalloc<float>(c, (size_t)M8 * 128);

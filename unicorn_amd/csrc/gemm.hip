@@ -388,9 +388,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_p44_supported(a) && !no_p44) cfg = 144;
     if (cfg == 144 && !gemm_p44_supported(a)) cfg = 44;
     if (cfg == 144) return launch_gemm_p44(a, s);
-    if (cfg == 88 && !gemm_pipe_supported(a)) cfg = 44;
     if (!a.epi && (cfg == 44 || cfg == 42 || cfg == 24)) cfg = 22;
-    if (cfg == 88) return launch_gemm_pipe(a, s);
 #define GOS(WM, WN, TM, TN, BK, NS) return conv ? launch_cfg<WM, WN, TM, TN, BK, true, NS>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false, NS>(a, s)
     if (!a.epi && (cfg == 444 || cfg == 445)) cfg = 22;
     switch (cfg) {

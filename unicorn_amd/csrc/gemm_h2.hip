@@ -36,13 +36,14 @@ __device__ u32x4 g_zero_page_h2 = {0u, 0u, 0u, 0u};
 
 #include "gemm_epi.h"
 
-template <int WM, int WN, int TM, int TN, bool CONV, bool STATS>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_h2_kernel(GemmArgs p) {
+template <int WM, int WN, int TM, int TN, bool CONV, bool STATS, int BKE = 32>
+__global__ __launch_bounds__(64 * WM * WN, (BKE == 16 ? 2 : 1)) void gemm_h2_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int BKE = 32;                  // k per step
-    constexpr int ROWB = 128;                // LDS row bytes = BKE x (2 B hi + 2 B lo)
-    constexpr int RPP = 8;                   // rows per 1-KiB DMA piece
+    constexpr int ROWB = 4 * BKE;            // LDS row bytes = BKE (k per step: 32 or 16) x (2 B hi + 2 B lo)
+    constexpr int CPR = ROWB / 16;           // 16-B chunks per LDS row (8 or 4)
+    constexpr int RPP = 64 / CPR;            // rows per 1-KiB DMA piece (8 or 16)
+    constexpr int SW = BKE == 32 ? 1 : 2;    // swizzle: chunk' = chunk ^ ((row >> SW) & (CPR-1))  (256-B bank period, see gemm.hip)
     constexpr int A_PC = BM / RPP / NW, B_PC = BN / RPP / NW;
     static_assert(A_PC >= 1 && B_PC >= 1, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_h2_kernel(GemmArgs p) {
 
     // ---- per-lane DMA sources: lane -> row lane/8 of its piece, physical chunk lane%8, logical chunk = phys ^ ((row>>1)&7);
     // logical chunk lc -> k group lc>>1 (8 k), half lc&1 (0 = hi, 1 = lo)
-    const int lrow = lane >> 3;
-    const int lch = (lane & 7) ^ (((RPP * wave + lrow) >> 1) & 7);
+    const int lrow = lane / CPR;
+    const int lch = (lane % CPR) ^ (((RPP * wave + lrow) >> SW) & (CPR - 1));
     const int kgrp = lch >> 1, half = lch & 1;
     const char* abase = reinterpret_cast<const char*>(p.A);
     const long zoff = reinterpret_cast<const char*>(&g_zero_page_h2) - abase;
@@ -140,39 +141,61 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_h2_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         __syncthreads();                                   // K slice kt landed (vmcnt(0) + barrier); everyone is done with buf^1
-        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        if (kt + 1 < nk && !(p.dbg & 1)) issue(kt + 1, buf ^ 1);     // dbg 1: ablation, no DMA after slice 0
+        if (p.dbg & 2) continue;                                     // dbg 2: ablation, DMA only
         const char* a = As + buf * BM * ROWB;
         const char* b = Bs + buf * BN * ROWB;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {                   // 16 k per MFMA; lane half fh carries k = 16 kk + 8 fh + (0..7)
-            const int ch = 2 * (2 * kk + fh);              // logical chunk of the hi halves; +1 = lo halves
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        // 16 k per MFMA; lane half fh carries k = 16 kk + 8 fh + (0..7); logical chunk 2 (2 kk + fh) holds the hi halves, +1 the lo
+        f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        auto ldfrag = [&](int kk, int slot) __attribute__((always_inline)) {
+            const int ch = 2 * (2 * kk + fh);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int row = wm * 32 * TM + i * 32 + fr, sw = (row >> 1) & 7;
-                ah[i] = *reinterpret_cast<const f16x8*>(a + row * ROWB + ((ch ^ sw) << 4));
-                al[i] = *reinterpret_cast<const f16x8*>(a + row * ROWB + (((ch + 1) ^ sw) << 4));
+                const int row = wm * 32 * TM + i * 32 + fr, sw = (row >> SW) & (CPR - 1);
+                ah[slot][i] = *reinterpret_cast<const f16x8*>(a + row * ROWB + ((ch ^ sw) << 4));
+                al[slot][i] = *reinterpret_cast<const f16x8*>(a + row * ROWB + (((ch + 1) ^ sw) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int row = wn * 32 * TN + j * 32 + fr, sw = (row >> 1) & 7;
-                bh[j] = *reinterpret_cast<const f16x8*>(b + row * ROWB + ((ch ^ sw) << 4));
-                bl[j] = *reinterpret_cast<const f16x8*>(b + row * ROWB + (((ch + 1) ^ sw) << 4));
+                const int row = wn * 32 * TN + j * 32 + fr, sw = (row >> SW) & (CPR - 1);
+                bh[slot][j] = *reinterpret_cast<const f16x8*>(b + row * ROWB + ((ch ^ sw) << 4));
+                bl[slot][j] = *reinterpret_cast<const f16x8*>(b + row * ROWB + (((ch + 1) ^ sw) << 4));
             }
+        };
+        // PF (8-wave 256 x 256 tile, 2 waves per SIMD): the fragments of sub-step 1 are read while the 24 MFMAs of sub-step 0
+        // issue (register double buffer); the 4-waves-per-SIMD tiles rely on wave interleaving instead (128-VGPR budget)
+        constexpr bool PF = TM * TN >= 8 && BKE == 32;
+        ldfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BKE / 16; ++kk) {
+            const int sl = PF ? kk : 0;
+            if (kk == 0 && PF) ldfrag(1, 1);
+            if (kk == 1 && !PF) ldfrag(1, 0);
             // swapped operands (weights = MFMA A): lane -> pixel row, 4 consecutive channels per accumulator quad
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[sl][j], ah[sl][i], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[sl][j], al[sl][i], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[sl][j], ah[sl][i], acc[i][j], 0, 0, 0);
         }
+    }
+    if (p.dbg & 16) {   // ablation: no epilogue (accumulators kept live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 1.2345e-30f && p.outF) p.outF[0] = sacc;
+        return;
     }
     if (p.wscale != 1.f) {
 #pragma unroll
@@ -185,21 +208,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_h2_kernel(GemmArgs p) {
     gemm_epilogue<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
-template <int WM, int WN, int TM, int TN, bool CONV>
+template <int WM, int WN, int TM, int TN, bool CONV, int BKE = 32>
 static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
-    size_t lds = (size_t)2 * (BM + BN) * 128;
+    size_t lds = (size_t)2 * (BM + BN) * 4 * BKE;
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (a.stats) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
-    else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return 0;
 }
 
@@ -231,9 +254,14 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
         else if (conv) cfg = b12 >= 400 ? 12 : 11;
         else cfg = b21 >= 400 ? 21 : 11;
     }
-    if (!a.epi && cfg == 44) cfg = 22;
+    if (!a.epi && (cfg == 44 || cfg == 48 || cfg == 42)) cfg = 22;
+    // plain GEMMs that take the 256 x 256 tile go to the persistent variant (gemm_h2p.hip); 144 forces it
+    if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_h2p_supported(a) && !getenv("UNI_NO_H2P")) cfg = 144;
+    if (cfg == 144) return gemm_h2p_supported(a) ? launch_gemm_h2p(a, s) : (uni_set_error("gemm(h2): persistent variant does not support this problem"), -1);
 #define GOH(WM, WN, TM, TN) return conv ? launch_h2_cfg<WM, WN, TM, TN, true>(a, s) : launch_h2_cfg<WM, WN, TM, TN, false>(a, s)
     switch (cfg) {
+        case 42: return conv ? launch_h2_cfg<2, 2, 4, 2, true, 16>(a, s) : launch_h2_cfg<2, 2, 4, 2, false, 16>(a, s);   // 256 x 128, 4 waves of 128 x 64, 16-k steps (48 KiB LDS): TWO blocks per CU, one block's epilogue runs under the other's MFMAs
+        case 48: GOH(2, 4, 4, 2);     // 256 x 256, 8 waves (2 x 4) of 128 x 64 wave tiles, 128 KiB LDS, fragment prefetch
         case 44: GOH(4, 4, 2, 2);     // 256 x 256, 16 waves, 128 KiB LDS
         case 22: GOH(2, 2, 2, 2);     // 128 x 128
         case 12: GOH(2, 2, 1, 2);     // 64 x 128

@@ -258,8 +258,10 @@ static int launch_p44_inst(const GemmArgs& a, int grid, hipStream_t s) {
     return 0;
 }
 
-bool gemm_p44_supported(const GemmArgs& a) {
-    return gemm_pipe_supported(a);      // same preconditions (plain GEMM, K % 64 == 0, bias, none/relu/gelu, aligned operands)
+bool gemm_p44_supported(const GemmArgs& a) {      // plain GEMM, K % 64 == 0, bias, none/relu/gelu on every column, aligned operands
+    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    return !conv && !a.stats && a.b32 == FMT_BF16 && a.epi && a.K == a.Kpad && a.bias && a.act_col0 == 0 && a.out_hw == 0 &&
+           (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_GELU) && (a.outF || a.outB) && (a.outF || !a.res);
 }
 
 int launch_gemm_p44(const GemmArgs& a, hipStream_t s) {

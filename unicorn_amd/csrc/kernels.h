@@ -31,10 +31,10 @@ float f16_to_f32_host(uint16_t h);
 float h2_weight_scale(float maxabs);
 void pack_weight_h2_host(const float* w, int N, int Cin, int KH, int KW, const float* row_scale, float scale, uint16_t* out,
                          int Npad, int Kpad);
-int launch_gemm_pipe(const GemmArgs& a, hipStream_t s);
-bool gemm_pipe_supported(const GemmArgs& a);
-int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persistent 256x256 tiles, next tile prefetched before the drain
-bool gemm_p44_supported(const GemmArgs& a);   // gemm_pipe.hip: persistent 256x128 tiles, drain overlapped with the next tile
+int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persistent 256x256 tiles (bf16), next tile prefetched before the drain
+bool gemm_p44_supported(const GemmArgs& a);
+int launch_gemm_h2p(const GemmArgs& a, hipStream_t s);    // gemm_h2p.hip: the same for the split-f16 format
+bool gemm_h2p_supported(const GemmArgs& a);
 
 // ---------------------------------------------------------------- norm.hip
 // Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.

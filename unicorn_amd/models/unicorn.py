@@ -64,8 +64,9 @@ class UnicornHead:
     def _run(self, xin, mask_in, mode):
         if mode not in ("sot", "mot"):
             raise ValueError("""mode has to be 'sot' or 'mot'""")        # unicorn_head.py:292
-        if not self.decode_in_inference:
-            raise ValueError("decode_in_inference=False is not supported")
+        raw = not self.decode_in_inference          # tools/export_torchscript.py:66: undecoded rows (unicorn_head.py:436-439)
+        if raw and self._m.mask:
+            raise ValueError()                       # unicorn_head_mask.py:470: the mask head has no undecoded path
         m = self._m
         m._require_ready()
         f = [nhwc(x) for x in xin]
@@ -89,7 +90,7 @@ class UnicornHead:
             mf = empty_nhwc(8, H // 8, W // 8, dev, B)
             um = empty_nhwc(9 * m.up_rate ** 2, H // 8, W // 8, dev, B)
         L.check(L.lib().uni_head(m._ctx, L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(pri[0]), L.ptr(pri[1]), L.ptr(pri[2]),
-                                 B, H, W, 0 if mode == "sot" else 1, L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
+                                 B, H, W, (0 if mode == "sot" else 1) | (2 if raw else 0), L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
                                  L.stream_ptr()), "uni_head")
         self.hw = [tuple(x.shape[2:]) for x in f]
         return out, dyn, mf, um
