@@ -106,6 +106,13 @@ int uni_upsample(uni_ctx* ctx, const float* feat, int B, int h, int w, float* em
 int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
              const float* prior16, const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params,
              float* mask_feats, float* up_masks, uni_stream_t stream);
+/* Object-batched head (VOS, external/lib/test/tracker/unicorn_vos.py:178-200 runs the head once per object on the SAME
+ * FPN maps): ONE image, K prior sets prior*: (K, H/s*W/s).  The prior enters only at x = stem(fpn) + prior*beta
+ * (unicorn_head.py:272-277), so FPN casts, stem convs and the mask branch run once and the rest over K samples.
+ * out (K, A, 5+nc), dyn_params (K, A, 169); mask_feats / up_masks are those of the ONE image (1, ...). */
+int uni_head_objects(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
+                     const float* prior16, const float* prior32, int K, int H, int W, int mode, float* out,
+                     float* dyn_params, float* mask_feats, float* up_masks, uni_stream_t stream);
 int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream);
 
 /* ---- context-free operators ------------------------------------------------------------------------- */
@@ -156,6 +163,27 @@ size_t uni_postprocess_workspace_bytes(int A);
 int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
                     int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* workspace, size_t workspace_bytes,
                     uni_stream_t stream);
+
+/* ---- mask post-processing of the VOS / MOTS drivers -------------------------------------------- */
+/* masks (N,Hn,Wn) fp32 at network resolution -> F.interpolate(scale_factor=1/r, bilinear, align_corners=False)[:, :H, :W]
+ * pasted into zero (N,H,W) maps: out_prob fp32 (external/lib/test/tracker/unicorn_vos.py:146-150) and / or
+ * out_bin = prob > thr as bytes (unicorn/evaluators/mot_evaluator.py:803-804).  Either output may be NULL. */
+int uni_mask_resize(const float* masks, int N, int Hn, int Wn, double r, int H, int W, float thr, float* out_prob,
+                    uint8_t* out_bin, uni_stream_t stream);
+/* Soft aggregation of unicorn_vos.py:99-121 fused with that resize: probs (K1,Hn,Wn) of the tracked objects (ids prob_ids, in
+ * cur_obj_ids order), init_masks (K2,H,W) {0,1} of objects introduced in this frame (ids init_ids); background =
+ * prod(1 - p), argmax over [background, ids] (numpy first-maximum rule) -> out (H,W) uint8 id map. */
+int uni_vos_merge(const float* probs, const int32_t* prob_ids, int K1, int Hn, int Wn, double r, const uint8_t* init_masks,
+                  const int32_t* init_ids, int K2, int H, int W, uint8_t* out, uni_stream_t stream);
+/* mot_evaluator.py:852-859: masks (N,H,W) {0,1} in track order -> a pixel stays with the first mask that claims it. */
+int uni_mots_overlap_free(const uint8_t* masks, int N, int H, int W, uint8_t* out, uni_stream_t stream);
+/* pycocotools rleEncode + rleToString of np.asfortranarray(mask) (mot_evaluator.py:884-890): out_chars (N,max_chars) bytes,
+ * out_len (N) string lengths (-1: more than max_runs runs or max_chars chars, retry with larger bounds); optional
+ * counts (N,max_runs+1) uint32 run lengths and n_runs (N). */
+size_t uni_rle_workspace_bytes(int N, int H, int W, int max_runs);
+int uni_rle_encode(const uint8_t* masks, int N, int H, int W, int max_runs, int max_chars, uint8_t* out_chars,
+                   int32_t* out_len, uint32_t* counts, int32_t* n_runs, void* workspace, size_t workspace_bytes,
+                   uni_stream_t stream);
 
 /* ---- low-level building blocks (exported for kernel parity tests) --------------------------------------- */
 /* out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+res).  A: bf16 NHWC map (Hin,Win,Cin) row stride lda.

@@ -568,18 +568,17 @@ def vos_init(P, cfg, img0: Tensor, boxes_xyxy: dict):
     return {"dict_pre": d_pre, "lbs": {k: label_map_s8(b, H, W) for k, b in boxes_xyxy.items()}}
 
 
-def vos_step(P, cfg, state, img: Tensor, conf_thre: float = 0.001, nms_thre: float = 0.65, max_inst: int = 1):
-    """unicorn_vos.py:157-200 (get_det_results) + the per-object selection of :123-155: interaction / upsample / one
-    correlation per frame, then PER OBJECT: propagate its label map, head(mode="sot"), postprocess_inst, keep the best
+def vos_group_results(P, cfg, fpn, d_cur, d_pre, lbs: dict, obj_ids, H: int, W: int, conf_thre: float = 0.001,
+                      nms_thre: float = 0.65):
+    """unicorn_vos.py:157-200 (get_det_results) + the per-object selection of :123-155 for ONE reference group: interaction /
+    upsample / one correlation, then PER OBJECT: propagate its label map, head(mode="sot"), postprocess_inst, keep the best
     instance.  Returns {obj_id: (det row (7,) | None, mask (H, W) probabilities at network resolution | None)}."""
-    fpn, d_cur = forward_backbone(P, cfg, img)
-    f_pre, f_cur = forward_interaction(P, state["dict_pre"], d_cur)
+    f_pre, f_cur = forward_interaction(P, d_pre, d_cur)
     e_pre, e_cur = forward_upsample(P, f_pre), forward_upsample(P, f_cur)
     dh, dw = d_cur["h"] * 2, d_cur["w"] * 2
-    H, W = img.shape[-2:]
     out = {}
-    for obj_id, lbs in state["lbs"].items():
-        pred = correlation_propagate(e_pre.flatten(-2)[0], e_cur.flatten(-2)[0], lbs)
+    for obj_id in obj_ids:
+        pred = correlation_propagate(e_pre.flatten(-2)[0], e_cur.flatten(-2)[0], lbs[obj_id])
         coarse = pred.view(1, -1, dh, dw).float()
         head_out = head_mask_forward(P, cfg, fpn, prior_pyramid(coarse), "sot")
         det, masks = postprocess_inst(cfg, head_out, 1, conf_thre, nms_thre)
@@ -591,6 +590,52 @@ def vos_step(P, cfg, state, img: Tensor, conf_thre: float = 0.001, nms_thre: flo
         det[:, 1:4:2] = det[:, 1:4:2].clamp(min=0, max=H)
         out[obj_id] = (det[0], masks[0, 0])
     return out
+
+
+def vos_step(P, cfg, state, img: Tensor, conf_thre: float = 0.001, nms_thre: float = 0.65, max_inst: int = 1):
+    """one frame for the objects of the first frame (single reference group): see vos_group_results"""
+    fpn, d_cur = forward_backbone(P, cfg, img)
+    H, W = img.shape[-2:]
+    return vos_group_results(P, cfg, fpn, d_cur, state["dict_pre"], state["lbs"], list(state["lbs"].keys()), H, W, conf_thre, nms_thre)
+
+
+def vos_track_init(P, cfg, img0: Tensor, boxes_xyxy: dict, out_hw, r: float = 1.0):
+    """unicorn_vos.py:43-69: boxes are given on the ORIGINAL image (xyxy), the network sees them scaled by r."""
+    _, d_pre = forward_backbone(P, cfg, img0)
+    Hn, Wn = img0.shape[-2:]
+    return {"groups": [(d_pre, list(boxes_xyxy.keys()))], "lbs": {k: label_map_s8(b * r, Hn, Wn) for k, b in boxes_xyxy.items()},
+            "H": int(out_hw[0]), "W": int(out_hw[1])}
+
+
+def vos_track_frame(P, cfg, state, img: Tensor, info: Optional[dict] = None, r: float = 1.0):
+    """unicorn_vos.py:71-121 (track) incl. the reference groups of objects that appear mid-sequence (:79-98): every group =
+    (backbone dict of the frame where its objects were introduced, their ids).  info (optional): {"init_object_ids": [...],
+    "init_bbox": {id: xyxy on the original image}, "init_mask": (H, W) integer id map}.  Returns the (H, W) uint8 id map."""
+    import numpy as np
+    info = info or {}
+    H, W = state["H"], state["W"]
+    Hn, Wn = img.shape[-2:]
+    fpn, d_cur = forward_backbone(P, cfg, img)
+    final = {}
+    for d_pre, ids in state["groups"]:                                              # :80-85
+        res = vos_group_results(P, cfg, fpn, d_cur, d_pre, state["lbs"], ids, Hn, Wn)
+        for k in ids:                                                               # get_mask_results :123-155
+            m = res[k][1]
+            if m is None:
+                final[k] = np.zeros((H, W), dtype=np.uint8)
+                continue
+            up = F.interpolate(m[None, None], scale_factor=1 / r, mode="bilinear", align_corners=False)[:, 0, :H, :W]
+            full = np.zeros((H, W), dtype=np.float32)
+            full[:up.shape[1], :up.shape[2]] = up[0].numpy()
+            final[k] = full
+    cur_ids = [k for _, ids in state["groups"] for k in ids]
+    if "init_object_ids" in info:                                                   # :87-98
+        state["groups"].append((d_cur, list(info["init_object_ids"])))
+        for k in info["init_object_ids"]:
+            state["lbs"][k] = label_map_s8(info["init_bbox"][k] * r, Hn, Wn)
+            final[k] = (np.asarray(info["init_mask"]) == int(k))
+        cur_ids = cur_ids + list(info["init_object_ids"])
+    return vos_merge({k: final[k] for k in cur_ids}, H, W)                           # :99-121
 
 
 def vos_merge(prob: dict, H: int, W: int):

@@ -599,3 +599,62 @@ def test_gemm_h2_persistent(L, cfg, case):
     if use_B:
         dec, _, _ = h2_decode(outB, M, N)
         assert ((dec.double() - exp).abs() <= tol * 1.2 + exp.abs() * 2.0 ** -21).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# mask post-processing on the device (row N1): integer / byte work -> BIT-EXACT against oracle/mask_oracle.py
+# ------------------------------------------------------------------------------------------------
+import mask_oracle as mo  # noqa: E402
+
+
+@pytest.mark.parametrize("geo", [(80, 128, 0.5, 160, 256), (96, 160, 0.8333333, 110, 190), (100, 160, 1.37, 70, 100),
+                                 (100, 160, 1.0, 100, 160), (50, 64, 0.7, 90, 40)])
+def test_mask_resize_device(L, geo):
+    from unicorn_amd.ops import mask_resize
+    Hn, Wn, r, H, W = geo
+    m = torch.rand(4, Hn, Wn, generator=torch.Generator().manual_seed(Hn + W))
+    ref = mo.resize_bilinear(m.numpy(), r, H, W)
+    got = mask_resize(m.cuda(), r, H, W).cpu().numpy()
+    assert np.array_equal(got, ref)                                            # same fp32 operation order, no FMA contraction
+    assert np.array_equal(mask_resize(m.cuda(), r, H, W, thr=0.3).cpu().numpy(), (ref > np.float32(0.3)).astype(np.uint8))
+    assert mask_resize(m[:0].cuda(), r, H, W).shape == (0, H, W)
+
+
+def test_vos_merge_device(L):
+    from unicorn_amd.ops import vos_merge
+    g = np.random.default_rng(3)
+    Hn, Wn, r, H, W = 100, 160, 0.75, 130, 200
+    probs = g.random((4, Hn, Wn), dtype=np.float32)
+    probs[0, :20] = 0.0
+    probs[1, 20:40] = 1.0                                                      # background exactly 0 there
+    probs[2] = probs[3]                                                        # exact ties between two objects: the lower id wins
+    ids = ["4", "2", "9", "6"]
+    init = (g.random((2, H, W)) > 0.8).astype(np.uint8)
+    ref = mo.soft_aggregate(mo.resize_bilinear(probs, r, H, W), ids, init, ["11", "1"])
+    got = vos_merge(torch.from_numpy(probs).cuda(), ids, r, H, W, torch.from_numpy(init).cuda(), ["11", "1"]).cpu().numpy()
+    assert np.array_equal(got, ref)
+    ref2 = mo.soft_aggregate(mo.resize_bilinear(probs, r, H, W), ids)
+    assert np.array_equal(vos_merge(torch.from_numpy(probs).cuda(), ids, r, H, W).cpu().numpy(), ref2)
+
+
+def test_mots_overlap_free_and_rle_device(L):
+    from unicorn_amd.ops import mots_overlap_free, rle_encode
+    g = np.random.default_rng(4)
+    H, W = 135, 241
+    masks = np.zeros((6, H, W), dtype=np.uint8)
+    for n in range(5):
+        y0, x0 = g.integers(0, H - 40), g.integers(0, W - 60)
+        masks[n, y0:y0 + g.integers(10, 40), x0:x0 + g.integers(10, 60)] = 1
+    masks[3] |= (g.random((H, W)) < 0.05).astype(np.uint8)                     # speckle: many short runs
+    masks[4, 0, 0] = 1                                                         # first column-major element set: leading zero-length run
+    # masks[5] stays empty: one run of h*w zeros
+    of = mots_overlap_free(torch.from_numpy(masks).cuda())
+    assert np.array_equal(of.cpu().numpy(), mo.overlap_free(masks))
+    strs = rle_encode(of)
+    exp = [mo.mask_to_rle_string(m) for m in mo.overlap_free(masks)]
+    assert strs == exp
+    for s, m in zip(strs, mo.overlap_free(masks)):                             # and they decode back through the rleFrString restatement
+        assert np.array_equal(mo.rle_decode(mo.rle_from_string(s), H, W), m)
+    assert rle_encode(of[:0]) == []
+    dense = (g.random((2, 64, 96)) < 0.5).astype(np.uint8)                      # > max_runs runs: the wrapper retries with larger bounds
+    assert rle_encode(torch.from_numpy(dense).cuda(), max_runs=64) == [mo.mask_to_rle_string(m) for m in dense]

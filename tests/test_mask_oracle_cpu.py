@@ -1,0 +1,65 @@
+"""oracle/mask_oracle.py (row N1 restatements) pinned on the CPU: the bilinear resize against torch's own F.interpolate, the
+soft aggregation against the literal numpy lines of unicorn_vos.py:99-121, the RLE codec by hand-derived strings and the
+encode -> decode round trip through the independent rleFrString restatement."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import mask_oracle as mo
+import unicorn_oracle as uo
+
+
+def test_resize_matches_torch_interpolate():
+    g = torch.Generator().manual_seed(0)
+    for (Hn, Wn, r, H, W) in [(80, 128, 0.5, 160, 256), (96, 160, 0.8333333, 110, 190), (64, 64, 1.0, 64, 64), (100, 160, 1.37, 70, 100)]:
+        m = torch.rand(3, Hn, Wn, generator=g)
+        ref = F.interpolate(m[:, None], scale_factor=1 / r, mode="bilinear", align_corners=False)[:, 0, :H, :W]
+        got = mo.resize_bilinear(m.numpy(), r, H, W)
+        assert got.shape == (3, H, W)
+        hh, ww = ref.shape[1:]
+        assert np.abs(got[:, :hh, :ww] - ref.numpy()).max() < 2e-7
+        assert (got[:, hh:] == 0).all() and (got[:, :, ww:] == 0).all()
+
+
+def test_soft_aggregate_matches_reference_lines():
+    g = np.random.default_rng(1)
+    H, W = 40, 56
+    probs = g.random((3, H, W), dtype=np.float32)
+    probs[0, :5] = 0.0
+    probs[1, 5:9] = 1.0
+    ids = ["2", "5", "3"]
+    init = (g.random((1, H, W)) > 0.7)
+    got = mo.soft_aggregate(probs, ids, init, ["7"])
+    d = {k: probs[i] for i, k in enumerate(ids)}
+    d["7"] = init[0]
+    assert np.array_equal(got, uo.vos_merge(d, H, W))                 # the restatement of unicorn_vos.py:99-121 used by the model tests
+
+
+def test_rle_hand_checked_and_round_trip():
+    assert mo.rle_string(np.array([4])) == b"4"                          # 2x2 zeros
+    assert mo.mask_to_rle_string(np.ones((2, 2))) == b"04"
+    assert mo.rle_string(np.array([33])) == b"Q1"                        # 33 = 1 + 32: low group 1 with continuation (1|32+48='Q'), then 1
+    assert mo.rle_string(np.array([5, 3, 7, 1])) == b"537N"              # 4th count is coded as 1 - 3 = -2 -> 0b11110 + 48 = 'N'
+    m = np.zeros((3, 4), dtype=np.uint8)
+    m[1, 0] = m[2, 0] = m[0, 1] = 1                                      # column-major sequence 0 1 1 | 1 0 0 | 0 ... -> runs 1, 3, 8
+    assert mo.rle_encode(m).tolist() == [1, 3, 8]
+    g = np.random.default_rng(2)
+    for shape in [(1, 1), (7, 13), (37, 29), (120, 200)]:
+        for dens in (0.0, 0.02, 0.5, 1.0):
+            mk = (g.random(shape) < dens).astype(np.uint8)
+            if shape == (120, 200):                                      # blobs: long runs, large deltas
+                mk[30:90, 50:140] = 1
+            s = mo.mask_to_rle_string(mk)
+            cn = mo.rle_from_string(s)
+            assert np.array_equal(cn, mo.rle_encode(mk).astype(np.int64))
+            assert np.array_equal(mo.rle_decode(cn, *shape), mk)
+
+
+def test_overlap_free():
+    m = np.zeros((3, 2, 4), dtype=np.uint8)
+    m[0, 0, :2] = 1
+    m[1, 0, 1:3] = 1
+    m[2, :, :] = 1
+    o = mo.overlap_free(m)
+    assert o[0].tolist() == [[1, 1, 0, 0], [0, 0, 0, 0]] and o[1].tolist() == [[0, 0, 1, 0], [0, 0, 0, 0]]
+    assert o[2].tolist() == [[0, 0, 0, 1], [1, 1, 1, 1]] and (o.sum(0) <= 1).all()

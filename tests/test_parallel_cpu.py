@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    from unicorn_amd.parallel import ROW, gather_result_rows, shard_streams
+    from unicorn_amd.parallel import ROW, gather_byte_strings, gather_result_rows, shard_streams
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,7 +24,11 @@ def _worker(rank, world, port, q):
     rows = torch.tensor(rows, dtype=torch.float32).reshape(-1, ROW)
     out = gather_result_rows(rows)
     empty = gather_result_rows(torch.zeros((0, ROW)) if rank == 1 else rows)     # a rank with no rows
-    q.put((rank, streams, out.clone(), empty.shape[0], rows.shape[0]))
+    # variable-length payloads (mask RLE strings): ragged item counts AND ragged item lengths, one rank may have none
+    mine = [bytes([65 + rank]) * (3 + 5 * i + rank) for i in range(4 - 3 * rank)]
+    strs = gather_byte_strings(mine)
+    none = gather_byte_strings([] if rank == 0 else mine)
+    q.put((rank, streams, out.clone(), empty.shape[0], rows.shape[0], strs, none))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,6 +51,9 @@ def test_stream_sharding_and_gather_world2():
     key = a[:, 0] * 100 + a[:, 1]
     assert torch.equal(key, torch.sort(key)[0])                    # ordered by (stream, frame)
     assert res[0][3] == res[0][4] and res[1][3] == res[0][4]       # ragged: one rank contributed zero rows
+    exp = [[b"A" * (3 + 5 * i) for i in range(4)], [b"B" * 4]]
+    assert res[0][5] == exp and res[1][5] == exp                   # byte strings: same nested list on every rank, rank order
+    assert res[0][6] == [[], [b"B" * 4]] and res[1][6] == [[], [b"B" * 4]]
 
 
 def test_single_process_is_identity():

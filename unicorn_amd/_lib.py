@@ -31,6 +31,7 @@ PROTOS = {
     "uni_interaction": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_upsample": (c_i, [C.c_void_p, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
     "uni_head": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
+    "uni_head_objects": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),
     "uni_pos_embed": (c_i, [C.c_void_p, c_i, c_i, c_f, C.c_void_p]),
     "uni_msda_fwd": (c_i, [c_f, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                            C.c_void_p]),
@@ -46,6 +47,11 @@ PROTOS = {
     "uni_postprocess": (c_i, [c_f, c_i, c_i, c_i, C.c_float, C.c_float, c_i, c_i, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uni_sample_embeddings": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, C.c_float, c_f, C.c_void_p]),
     "uni_condinst_masks": (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uni_mask_resize": (c_i, [c_f, c_i, c_i, c_i, C.c_double, c_i, c_i, C.c_float, c_f, c_f, C.c_void_p]),
+    "uni_vos_merge": (c_i, [c_f, c_f, c_i, c_i, c_i, C.c_double, c_f, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
+    "uni_mots_overlap_free": (c_i, [c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
+    "uni_rle_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i, c_i]),
+    "uni_rle_encode": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uni_pack_weight": (c_i, [C.c_void_p, c_i, c_i, c_i, c_i, C.c_void_p]),
     "uni_gemm_bf16": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i,
                             c_f, c_i, c_i, C.c_void_p]),

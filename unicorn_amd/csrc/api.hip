@@ -94,7 +94,14 @@ int uni_head(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fp
              uni_stream_t stream) {
     UNI_REQUIRE(ctx && fpn0 && fpn1 && fpn2 && prior8 && prior16 && prior32 && out, "head: NULL argument");
     UNI_REQUIRE(mode >= 0 && mode <= 3, "head: mode %d (bit 0: 0 = sot / 1 = mot, bit 1: raw outputs, decode_in_inference = False)", mode);
-    API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, B, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
+    API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, B, 1, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
+}
+int uni_head_objects(uni_ctx* ctx, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8, const float* prior16,
+                     const float* prior32, int K, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats,
+                     float* up_masks, uni_stream_t stream) {
+    UNI_REQUIRE(ctx && fpn0 && fpn1 && fpn2 && prior8 && prior16 && prior32 && out, "head_objects: NULL argument");
+    UNI_REQUIRE(mode >= 0 && mode <= 3, "head_objects: mode %d", mode);
+    API(engine_head(ctx, fpn0, fpn1, fpn2, prior8, prior16, prior32, 1, K, H, W, mode, out, dyn_params, mask_feats, up_masks, S(stream)));
 }
 int uni_pos_embed(uni_ctx* ctx, int h, int w, float* out_nhwc, uni_stream_t stream) {
     UNI_REQUIRE(ctx && out_nhwc && h > 0 && w > 0, "pos_embed: bad argument");
@@ -162,6 +169,38 @@ int uni_condinst_masks(const float* mask_feats, const float* up_masks, const flo
     a.coarse_ws = a.logits_ws + (size_t)n * H8 * W8;
     a.out = out;
     API(launch_condinst(a, S(stream)));
+}
+
+// F.interpolate(scale_factor = 1/r): output size floor(in * (1/r)), source scale (float)(1 / (1/r)) (ATen compute_scales_value)
+static void resize_geometry(int Hn, int Wn, double r, int* ho, int* wo, float* rscale) {
+    const double sf = 1.0 / r;
+    *ho = (int)floor((double)Hn * sf);
+    *wo = (int)floor((double)Wn * sf);
+    *rscale = (float)(1.0 / sf);
+}
+int uni_mask_resize(const float* masks, int N, int Hn, int Wn, double r, int H, int W, float thr, float* out_prob, uint8_t* out_bin,
+                    uni_stream_t stream) {
+    UNI_REQUIRE((N == 0 || masks) && (out_prob || out_bin) && r > 0, "mask_resize: bad argument");
+    int ho, wo; float rs;
+    resize_geometry(Hn, Wn, r, &ho, &wo, &rs);
+    API(launch_mask_resize(masks, N, Hn, Wn, rs, ho, wo, H, W, thr, out_prob, out_bin, S(stream)));
+}
+int uni_vos_merge(const float* probs, const int32_t* prob_ids, int K1, int Hn, int Wn, double r, const uint8_t* init_masks,
+                  const int32_t* init_ids, int K2, int H, int W, uint8_t* out, uni_stream_t stream) {
+    UNI_REQUIRE(out && (K1 == 0 || (probs && prob_ids)) && (K2 == 0 || (init_masks && init_ids)) && r > 0, "vos_merge: bad argument");
+    int ho = 0, wo = 0; float rs = 1.f;
+    if (K1) resize_geometry(Hn, Wn, r, &ho, &wo, &rs);
+    API(launch_vos_merge(probs, prob_ids, K1, Hn, Wn, rs, ho, wo, init_masks, init_ids, K2, H, W, out, S(stream)));
+}
+int uni_mots_overlap_free(const uint8_t* masks, int N, int H, int W, uint8_t* out, uni_stream_t stream) {
+    UNI_REQUIRE(N == 0 || (masks && out), "overlap_free: NULL argument");
+    API(launch_overlap_free(masks, N, H, W, out, S(stream)));
+}
+size_t uni_rle_workspace_bytes(int N, int H, int W, int max_runs) { return rle_workspace_bytes(N, H, W, max_runs); }
+int uni_rle_encode(const uint8_t* masks, int N, int H, int W, int max_runs, int max_chars, uint8_t* out_chars, int32_t* out_len,
+                   uint32_t* counts, int32_t* n_runs, void* workspace, size_t workspace_bytes, uni_stream_t stream) {
+    UNI_REQUIRE(N == 0 || (masks && out_chars && out_len && workspace), "rle_encode: NULL argument");
+    API(launch_rle_encode(masks, N, H, W, max_runs, max_chars, out_chars, out_len, counts, n_runs, workspace, workspace_bytes, S(stream)));
 }
 
 int uni_pack_weight(const float* w, int N, int Cin, int KH, int KW, uint16_t* out) {

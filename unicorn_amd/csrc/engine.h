@@ -66,5 +66,5 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
 int engine_upsample(uni_ctx* c, const float* feat, int B, int h, int w, float* embed, hipStream_t s);
 int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s);
 int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8, const float* prior16,
-                const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
+                const float* prior32, int B, int K, int H, int W, int mode, float* out, float* dyn_params, float* mask_feats, float* up_masks,
                 hipStream_t s);

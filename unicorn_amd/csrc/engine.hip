@@ -679,15 +679,21 @@ int engine_pos_embed(uni_ctx* c, int h, int w, float* out, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // stage: unified head (+ mask branch / controllers)   (unicorn_head.py:249-336, unicorn_head_mask.py:280-372)
 // ------------------------------------------------------------------------------------------------
+// K > 1 = object-batched call (row N3, unicorn_vos.py:178-200): ONE image (B == 1) with K prior sets.  The prior only enters at
+// x = stem(fpn) + prior * beta (unicorn_head.py:272-277), so the FPN casts, the stem convs (+ their GroupNorm statistics) and the
+// whole mask branch run once; prior fusion, attention blocks, towers, predictions and controllers run over K "samples".
 int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* fpn2, const float* prior8,
-                const float* prior16, const float* prior32, int B, int H, int W, int mode, float* out, float* dyn_params,
+                const float* prior16, const float* prior32, int B, int K, int H, int W, int mode, float* out, float* dyn_params,
                 float* mask_feats, float* up_masks, hipStream_t s) {
     const bool raw = (mode & 2) != 0;     // decode_in_inference = False (unicorn_head.py:436-439): [reg, sigmoid(obj), sigmoid(cls)] rows undecoded
     mode &= 1;
     UNI_REQUIRE(mode == 0 || mode == 1, "head: mode has to be 0 ('sot') or 1 ('mot')");   // unicorn_head.py:291-292
     UNI_REQUIRE(H % 32 == 0 && W % 32 == 0, "head: H=%d W=%d", H, W);
-    UNI_REQUIRE(B >= 1 && B <= 64, "head: batch %d unsupported (1..64)", B);
+    UNI_REQUIRE(B >= 1 && B <= 64 && K >= 1 && K <= 64 && (K == 1 || B == 1), "head: batch %d x %d objects unsupported (B 1..64; K 1..64 with B = 1)", B, K);
+    const int Bi = B;                      // images
+    B = Bi * K;                            // samples of the per-object part
     RUN(stage_begin(c, B, H, W, s));
+    c->nb = Bi;
     const auto& cfg = c->cfg;
     if (cfg.mask) UNI_REQUIRE(dyn_params && mask_feats && up_masks, "head: mask model needs dyn_params/mask_feats/up_masks");
     const int ch[3] = {cfg.dims[1], cfg.dims[2], cfg.dims[3]};
@@ -699,8 +705,8 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     const int ncls = mode == 0 ? 1 : cfg.num_classes, nch = 5 + ncls;
     ActPtr fb[3];
     for (int k = 0; k < 3; ++k) {
-        fb[k] = actalloc(c, (size_t)B * HWk[k] * ch[k]);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], B * HWk[k], ch[k], s, c->b32); }));
+        fb[k] = actalloc(c, (size_t)Bi * HWk[k] * ch[k]);
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Bi * HWk[k], ch[k], s, c->b32); }));
     }
     // The three FPN levels are independent until the decode: run them concurrently (the stride-16/32 levels are
     // far too small to fill 256 CUs on their own).  Level k gets its own stream and a disjoint workspace slice.
@@ -720,7 +726,29 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         if (fork) { s = k == 0 ? s_main : c->aux[k - 1]; c->ws_off = lvl_base + (size_t)k * slice_bytes; }
         const size_t mark = c->ws_off;
         float* x = wsalloc<float>(c, (size_t)M * 256);
-        { Out o; o.F = x; o.ldf = 256; o.prior = prior[k]; o.pbeta = c->beta[k]; RUN(run_baseconv(c, c->stems[k], fb[k], ch[k], Hk[k], Wk[k], o, s)); }
+        if (K == 1) {
+            c->nb = Bi;
+            Out o; o.F = x; o.ldf = 256; o.prior = prior[k]; o.pbeta = c->beta[k];
+            RUN(run_baseconv(c, c->stems[k], fb[k], ch[k], Hk[k], Wk[k], o, s));
+        } else {   // stem conv + statistics once, GroupNorm-apply + SiLU + prior fusion once per object
+            c->nb = 1;
+            const size_t mk = c->ws_off;
+            GemmArgs g = conv_args(c->stems[k].conv, fb[k], ch[k], Hk[k], Wk[k], 1, 0, 1);
+            float* raw = wsalloc<float>(c, (size_t)g.M * g.N);
+            double* st = next_stats(c, 1);
+            g.outF = raw; g.ldf = g.N; g.stats = st; g.cpg = g.N / 16;
+            RUN(p_gemm(c, g, s));
+            for (int ko = 0; ko < K; ++ko) {
+                GnApplyArgs a;
+                a.x = raw; a.ldx = g.N; a.stats = st; a.gamma = c->stems[k].gn.g; a.beta = c->stems[k].gn.b; a.eps = 1e-3f;
+                a.M = HWk[k]; a.B = 1; a.C = 256; a.G = 16; a.act = ACT_SILU;
+                a.prior = prior[k] + (size_t)ko * HWk[k]; a.prior_beta = c->beta[k];
+                a.outF = x + (size_t)ko * HWk[k] * 256; a.ldf = 256; a.W = Wk[k];
+                RUN(p_gn(c, a, s));
+            }
+            (void)mk;       // raw stays allocated until the level's slice is released (the gn_apply launches read it)
+        }
+        c->nb = B;
         ActPtr t = actalloc(c, (size_t)M * 256);
         ActPtr hid = actalloc(c, (size_t)M * 1024);
         ActPtr xb = actalloc(c, (size_t)M * 256);
@@ -767,15 +795,16 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         c->ws_off = lvl_base + 3 * slice_bytes;
     }
     if (!raw) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, HWk[0], Wk[0], HWk[1], Wk[1], HWk[2], Wk[2], nch, s, B); }));
-    if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162
-        const int M8 = B * HWk[0];
+    if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162 (depends on the FPN maps only: once per IMAGE)
+        c->nb = Bi;
+        const int M8 = Bi * HWk[0];
         float* xm = wsalloc<float>(c, (size_t)M8 * 128);
         for (int k = 0; k < 3; ++k) {
-            const int M = B * HWk[k];
+            const int M = Bi * HWk[k];
             float* r = k == 0 ? xm : wsalloc<float>(c, (size_t)M * 128);
             Out o; o.F = r; o.ldf = 128;
             RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
-            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s, B); }));
+            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s, Bi); }));
         }
         ActPtr xmb = actalloc(c, (size_t)M8 * 128);
         RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
@@ -788,7 +817,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         }
         { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(p_gemm(c, g, s)); }
         ActPtr u = tb[0] == cur ? tb[1] : tb[0];
-        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1, B); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
+        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1, Bi); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
         { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(p_gemm(c, g, s)); }
     }
     return 0;

@@ -138,5 +138,14 @@ int launch_nms(const float* boxes, const float* scores, int n, float iou_thr, in
                size_t ws_bytes, hipStream_t s);
 int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
                        int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t s);
+// mask_post.hip: mask post-processing of the VOS / MOTS drivers (row N1)
+int launch_mask_resize(const float* masks, int N, int Hn, int Wn, float rscale, int ho, int wo, int H, int W, float thr, float* outF,
+                       unsigned char* outU, hipStream_t s);
+int launch_vos_merge(const float* probs, const int* prob_ids, int K1, int Hn, int Wn, float rscale, int ho, int wo,
+                     const unsigned char* init_masks, const int* init_ids, int K2, int H, int W, unsigned char* out, hipStream_t s);
+int launch_overlap_free(const unsigned char* in, int N, int H, int W, unsigned char* out, hipStream_t s);
+size_t rle_workspace_bytes(int N, int H, int W, int max_runs);
+int launch_rle_encode(const unsigned char* masks, int N, int H, int W, int max_runs, int max_chars, unsigned char* out_chars,
+                      int* out_len, unsigned* counts, int* n_runs, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_add_pos_bf16(const float* src, const float* pos0, const float* pos1, const float* lvl, bf16* out, int hw,
                         int C, hipStream_t s, int b32 = 0, int B = 1);

@@ -1,0 +1,278 @@
+// Row N1 (remainder): mask post-processing of the VOS / MOTS drivers on the device -- integer / byte work, bit-exact against
+// oracle/mask_oracle.py:
+//   mask_resize_kernel     F.interpolate(mask, scale_factor=1/r, "bilinear", align_corners=False)[:, 0, :H, :W] pasted into a zero
+//                          (H, W) map; float output (unicorn_vos.py:146-150) or `> thr` bytes (mot_evaluator.py:803-804)
+//   vos_merge_kernel       the same resize fused with the soft aggregation of unicorn_vos.py:99-121: background = prod(1 - p),
+//                          argmax over [background, ids] -> (H, W) uint8 id map (never materialises the (H, W, K+1) float64 cube)
+//   overlap_free_kernel    mot_evaluator.py:852-859: a pixel stays with the first track that claims it
+//   rle_*                  pycocotools rleEncode (column-major runs) + rleToString (mot_evaluator.py:884-890)
+// HBM-bound streaming kernels: coalesced along x, one pass over the inputs.
+#include "kernels.h"
+
+// the float arithmetic below must round exactly like the numpy restatement: no fused multiply-add anywhere in this file
+#pragma clang fp contract(off)
+
+namespace {
+// ATen UpSample.h: area_pixel_compute_source_index (align_corners = false) + guard_index_and_lambda, fp32, plain operators under
+// `fp contract(off)` (the __fmul_rn-style wrappers are inlined from headers compiled WITH contraction and fuse anyway)
+// (the oracle repeats exactly this operation order in numpy)
+struct SrcIdx { int i0, i1; float w0, w1; };
+__device__ __forceinline__ SrcIdx src_index(int d, int n_in, float rscale) {
+    float real = rscale * ((float)d + 0.5f) - 0.5f;
+    real = fmaxf(real, 0.f);
+    int i0 = (int)floorf(real);
+    i0 = i0 < n_in - 1 ? i0 : n_in - 1;
+    float l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+    SrcIdx s;
+    s.i0 = i0;
+    s.i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    s.w0 = 1.f - l1;
+    s.w1 = l1;
+    return s;
+}
+__device__ __forceinline__ float bilerp(const float* m, int Wn, const SrcIdx& sy, const SrcIdx& sx) {
+    const float a = m[(size_t)sy.i0 * Wn + sx.i0], b = m[(size_t)sy.i0 * Wn + sx.i1];
+    const float c = m[(size_t)sy.i1 * Wn + sx.i0], d = m[(size_t)sy.i1 * Wn + sx.i1];
+    const float top = sx.w0 * a + sx.w1 * b;        // every product and sum rounds on its own (fp contract is off in this file)
+    const float bot = sx.w0 * c + sx.w1 * d;
+    return sy.w0 * top + sy.w1 * bot;
+}
+
+__global__ __launch_bounds__(256) void mask_resize_kernel(const float* __restrict__ m, int N, int Hn, int Wn, float rscale, int ho, int wo,
+                                                          int H, int W, float thr, float* __restrict__ outF,
+                                                          unsigned char* __restrict__ outU) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+    if (x >= W) return;
+    float v = 0.f;
+    if (y < ho && x < wo) v = bilerp(m + (size_t)n * Hn * Wn, Wn, src_index(y, Hn, rscale), src_index(x, Wn, rscale));
+    const size_t o = ((size_t)n * H + y) * W + x;
+    if (outF) outF[o] = v;
+    if (outU) outU[o] = v > thr ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void vos_merge_kernel(const float* __restrict__ probs, const int* __restrict__ prob_ids, int K1, int Hn, int Wn,
+                                                        float rscale, int ho, int wo, const unsigned char* __restrict__ init_masks,
+                                                        const int* __restrict__ init_ids, int K2, int H, int W,
+                                                        unsigned char* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const bool inside = y < ho && x < wo;
+    SrcIdx sy{}, sx{};
+    if (inside) { sy = src_index(y, Hn, rscale); sx = src_index(x, Wn, rscale); }
+    // np.argmax over channels [0 = background, id]: strictly greater replaces, on equality the LOWER channel index stays
+    float bg = 1.f, best = -1.f;
+    int best_id = 0x7fffffff;
+    for (int k = 0; k < K1; ++k) {
+        const float p = inside ? bilerp(probs + (size_t)k * Hn * Wn, Wn, sy, sx) : 0.f;
+        bg = bg * (1.f - p);
+        const int id = prob_ids[k];
+        if (p > best || (p == best && id < best_id)) { best = p; best_id = id; }
+    }
+    for (int k = 0; k < K2; ++k) {
+        const float p = init_masks[((size_t)k * H + y) * W + x] ? 1.f : 0.f;
+        bg = bg * (1.f - p);
+        const int id = init_ids[k];
+        if (p > best || (p == best && id < best_id)) { best = p; best_id = id; }
+    }
+    // channels of ids that are absent hold 0 and never beat the background (bg >= 0, index 0 wins ties)
+    out[(size_t)y * W + x] = (best > bg) ? (unsigned char)best_id : 0;
+}
+
+__global__ __launch_bounds__(256) void overlap_free_kernel(const unsigned char* __restrict__ in, int N, size_t HW, unsigned char* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    unsigned char prev = 0;
+    for (int n = 0; n < N; ++n) {
+        const unsigned char v = in[(size_t)n * HW + i] ? 1 : 0;
+        out[(size_t)n * HW + i] = v & (prev ^ 1);
+        prev |= v;
+    }
+}
+
+// ---- RLE.  Column-major element j = x * h + y of mask n is in[n][y][x].  A run starts at j when t[j] != t[j-1] (t[-1] := 0).
+// Pass 1 counts the starts per tile of RLE_TILE elements, pass 2 scans the tile counts (one block per mask), pass 3 writes
+// the start positions, pass 4 turns them into counts and per-run string lengths, pass 5 scans those and pass 6 writes chars.
+constexpr int RLE_TILE = 2048;     // elements per block (256 threads x 8)
+__device__ __forceinline__ unsigned char rle_elem(const unsigned char* m, int h, int w, long j) {
+    if (j < 0) return 0;
+    const int x = (int)(j / h), y = (int)(j - (long)x * h);
+    return m[(size_t)y * w + x] ? 1 : 0;
+}
+__device__ int block_excl_scan(int v, int* total, int* sh /* [256 / 64 + 1] */) {     // 256-thread exclusive scan
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base += sh[i];
+    if (total) *total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + inc - v;
+}
+__global__ __launch_bounds__(256) void rle_count_kernel(const unsigned char* __restrict__ in, int h, int w, int ntiles, int* __restrict__ tile_cnt) {
+    __shared__ int sh[5];
+    const int n = blockIdx.y, tile = blockIdx.x;
+    const unsigned char* m = in + (size_t)n * h * w;
+    const long a = (long)h * w, j0 = (long)tile * RLE_TILE + threadIdx.x * 8;
+    int c = 0;
+    unsigned char prev = rle_elem(m, h, w, j0 - 1);
+    for (int e = 0; e < 8; ++e) {
+        const long j = j0 + e;
+        if (j < a) { const unsigned char t = rle_elem(m, h, w, j); c += t != prev; prev = t; }
+    }
+    int total;
+    (void)block_excl_scan(c, &total, sh);
+    if (threadIdx.x == 0) tile_cnt[(size_t)n * ntiles + tile] = total;
+}
+// exclusive scan of a per-mask int array of length len (one block per mask, sequential over 256-wide chunks)
+__global__ __launch_bounds__(256) void rle_scan_kernel(int* __restrict__ v, int len, int stride, int* __restrict__ totals) {
+    __shared__ int sh[5];
+    __shared__ int carry;
+    int* p = v + (size_t)blockIdx.x * stride;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < len; base += 256) {
+        const int i = base + threadIdx.x;
+        const int x = i < len ? p[i] : 0;
+        int total;
+        const int ex = block_excl_scan(x, &total, sh);
+        const int cbase = carry;
+        if (i < len) p[i] = cbase + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cbase + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && totals) totals[blockIdx.x] = carry;
+}
+__global__ __launch_bounds__(256) void rle_starts_kernel(const unsigned char* __restrict__ in, int h, int w, int ntiles, const int* __restrict__ tile_off,
+                                                         int max_runs, int* __restrict__ starts) {
+    __shared__ int sh[5];
+    const int n = blockIdx.y, tile = blockIdx.x;
+    const unsigned char* m = in + (size_t)n * h * w;
+    const long a = (long)h * w, j0 = (long)tile * RLE_TILE + threadIdx.x * 8;
+    unsigned char t[8];
+    unsigned char prev = rle_elem(m, h, w, j0 - 1);
+    int c = 0;
+    unsigned flags = 0;
+    for (int e = 0; e < 8; ++e) {
+        const long j = j0 + e;
+        t[e] = j < a ? rle_elem(m, h, w, j) : prev;
+        if (j < a && t[e] != prev) { flags |= 1u << e; ++c; }
+        prev = t[e];
+    }
+    int off = tile_off[(size_t)n * ntiles + tile] + block_excl_scan(c, nullptr, sh);
+    for (int e = 0; e < 8; ++e)
+        if (flags & (1u << e)) {
+            if (off < max_runs) starts[(size_t)n * max_runs + off] = (int)(j0 + e);
+            ++off;
+        }
+}
+__device__ __forceinline__ int rle_delta(const int* starts, int nstart, long a, int i, int* cnt_i) {
+    // runs: cnt[0] = first start (or a), cnt[i] = start[i] - start[i-1], cnt[nstart] = a - start[nstart-1]
+    auto cnt = [&](int q) -> long {
+        const long lo = q == 0 ? 0 : starts[q - 1];
+        const long hi = q < nstart ? starts[q] : a;
+        return hi - lo;
+    };
+    const long c = cnt(i);
+    *cnt_i = (int)c;
+    return (int)(c - (i > 2 ? cnt(i - 2) : 0));
+}
+__device__ __forceinline__ int rle_chars(long x, unsigned char* dst) {      // maskApi.c rleToString inner loop
+    int n = 0;
+    bool more = true;
+    while (more) {
+        int c = (int)(x & 0x1f);
+        x >>= 5;
+        more = (c & 0x10) ? x != -1 : x != 0;
+        if (more) c |= 0x20;
+        if (dst) dst[n] = (unsigned char)(c + 48);
+        ++n;
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void rle_len_kernel(const int* __restrict__ starts, const int* __restrict__ nstarts, long a, int max_runs,
+                                                      int* __restrict__ lens, unsigned* __restrict__ counts) {
+    const int n = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = min(nstarts[n], max_runs);
+    if (i > ns) return;
+    int c;
+    const int x = rle_delta(starts + (size_t)n * max_runs, ns, a, i, &c);
+    lens[(size_t)n * (max_runs + 1) + i] = rle_chars(x, nullptr);
+    if (counts) counts[(size_t)n * (max_runs + 1) + i] = (unsigned)c;
+}
+__global__ __launch_bounds__(256) void rle_write_kernel(const int* __restrict__ starts, const int* __restrict__ nstarts, long a, int max_runs,
+                                                        const int* __restrict__ offs, int max_chars, unsigned char* __restrict__ out) {
+    const int n = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = min(nstarts[n], max_runs);
+    if (i > ns) return;
+    int c;
+    const int x = rle_delta(starts + (size_t)n * max_runs, ns, a, i, &c);
+    const int o = offs[(size_t)n * (max_runs + 1) + i];
+    unsigned char tmp[8];
+    const int len = rle_chars(x, tmp);
+    if (o + len <= max_chars)
+        for (int e = 0; e < len; ++e) out[(size_t)n * max_chars + o + e] = tmp[e];
+}
+}  // namespace
+
+int launch_mask_resize(const float* masks, int N, int Hn, int Wn, float rscale, int ho, int wo, int H, int W, float thr, float* outF,
+                       unsigned char* outU, hipStream_t s) {
+    if (N == 0) return 0;
+    UNI_REQUIRE(Hn > 0 && Wn > 0 && H > 0 && W > 0 && ho > 0 && wo > 0 && N <= 65535 && H <= 65535, "mask_resize: bad geometry");
+    hipLaunchKernelGGL(mask_resize_kernel, dim3(cdiv(W, 256), H, N), dim3(256), 0, s, masks, N, Hn, Wn, rscale, ho, wo, H, W, thr, outF, outU);
+    return 0;
+}
+int launch_vos_merge(const float* probs, const int* prob_ids, int K1, int Hn, int Wn, float rscale, int ho, int wo,
+                     const unsigned char* init_masks, const int* init_ids, int K2, int H, int W, unsigned char* out, hipStream_t s) {
+    UNI_REQUIRE(H > 0 && W > 0 && H <= 65535 && (K1 == 0 || (Hn > 0 && Wn > 0 && ho > 0 && wo > 0)), "vos_merge: bad geometry");
+    hipLaunchKernelGGL(vos_merge_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, s, probs, prob_ids, K1, Hn, Wn, rscale, ho, wo, init_masks,
+                       init_ids, K2, H, W, out);
+    return 0;
+}
+int launch_overlap_free(const unsigned char* in, int N, int H, int W, unsigned char* out, hipStream_t s) {
+    if (N == 0) return 0;
+    const size_t hw = (size_t)H * W;
+    hipLaunchKernelGGL(overlap_free_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, s, in, N, hw, out);
+    return 0;
+}
+size_t rle_workspace_bytes(int N, int H, int W, int max_runs) {
+    const size_t ntiles = ((size_t)H * W + RLE_TILE - 1) / RLE_TILE;
+    return ((size_t)N * (ntiles + (size_t)max_runs + 2 * ((size_t)max_runs + 1) + 2)) * sizeof(int) + 256;
+}
+__global__ void rle_finalize_kernel(const int* __restrict__ nstart, int N, int max_runs, int max_chars, int* __restrict__ out_len,
+                                    int* __restrict__ n_runs) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (n_runs) n_runs[n] = nstart[n] + 1;
+    if (nstart[n] > max_runs || out_len[n] > max_chars) out_len[n] = -1;        // overflow: the caller must retry with larger bounds
+}
+
+// masks (N, H, W) {0,1} bytes -> out_chars (N, max_chars) + out_len (N) [string length, or -1 when max_runs / max_chars overflow],
+// optional counts (N, max_runs + 1) uint32 + n_runs (N)
+int launch_rle_encode(const unsigned char* masks, int N, int H, int W, int max_runs, int max_chars, unsigned char* out_chars,
+                      int* out_len, unsigned* counts, int* n_runs, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (N == 0) return 0;
+    UNI_REQUIRE(H > 0 && W > 0 && max_runs > 0 && max_chars > 0 && N <= 65535, "rle: bad argument");
+    UNI_REQUIRE(ws_bytes >= rle_workspace_bytes(N, H, W, max_runs), "rle: workspace too small");
+    const long a = (long)H * W;
+    const int ntiles = (int)((a + RLE_TILE - 1) / RLE_TILE);
+    int* tile_cnt = reinterpret_cast<int*>(ws);                  // [N][ntiles] counts -> exclusive offsets
+    int* starts = tile_cnt + (size_t)N * ntiles;                 // [N][max_runs] run start positions (column-major element index)
+    int* lens = starts + (size_t)N * max_runs;                   // [N][max_runs + 1] chars per run -> exclusive offsets
+    int* nstart = lens + (size_t)N * (max_runs + 1);             // [N]
+    UNI_CHECK_HIP(hipMemsetAsync(lens, 0, (size_t)N * (max_runs + 1) * sizeof(int), s));
+    hipLaunchKernelGGL(rle_count_kernel, dim3(ntiles, N), dim3(256), 0, s, masks, H, W, ntiles, tile_cnt);
+    hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, tile_cnt, ntiles, ntiles, nstart);
+    hipLaunchKernelGGL(rle_starts_kernel, dim3(ntiles, N), dim3(256), 0, s, masks, H, W, ntiles, tile_cnt, max_runs, starts);
+    hipLaunchKernelGGL(rle_len_kernel, dim3(cdiv(max_runs + 1, 256), N), dim3(256), 0, s, starts, nstart, a, max_runs, lens, counts);
+    hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, lens, max_runs + 1, max_runs + 1, out_len);
+    hipLaunchKernelGGL(rle_write_kernel, dim3(cdiv(max_runs + 1, 256), N), dim3(256), 0, s, starts, nstart, a, max_runs, lens, max_chars, out_chars);
+    hipLaunchKernelGGL(rle_finalize_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, nstart, N, max_runs, max_chars, out_len, n_runs);
+    return 0;
+}

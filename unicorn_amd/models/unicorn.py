@@ -71,14 +71,14 @@ class UnicornHead:
         m._require_ready()
         f = [nhwc(x) for x in xin]
         Bp = mask_in[0].shape[0]
-        if f[0].shape[0] == 1 and Bp > 1:      # object-batched call (row N3): one image, Bp prior sets -> one head pass over Bp samples
-            f = [x.expand(Bp, -1, -1, -1).contiguous(memory_format=torch.channels_last) for x in f]
-        B = f[0].shape[0]
+        Bi = f[0].shape[0]
+        objects = Bi == 1 and Bp > 1           # object-batched call (row N3): ONE image, Bp prior sets (uni_head_objects)
+        B = Bp if objects else Bi
         H, W = f[0].shape[2] * 8, f[0].shape[3] * 8
         pri = []
         for k, p in enumerate(mask_in):
             if p.shape[1] != 1 or p.shape[0] != B:
-                raise ValueError("head: priors must be (B,1,H/s,W/s); run one object per call like the reference drivers")
+                raise ValueError("head: priors must be (B,1,H/s,W/s) (or (K,1,H/s,W/s) prior sets for ONE image)")
             pri.append(p.float().contiguous())
         nc = 1 if mode == "sot" else self.num_classes
         A = sum(x.shape[2] * x.shape[3] for x in f)
@@ -87,11 +87,12 @@ class UnicornHead:
         dyn = mf = um = None
         if m.mask:
             dyn = torch.empty((B, A, 169), device=dev, dtype=torch.float32)
-            mf = empty_nhwc(8, H // 8, W // 8, dev, B)
-            um = empty_nhwc(9 * m.up_rate ** 2, H // 8, W // 8, dev, B)
-        L.check(L.lib().uni_head(m._ctx, L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(pri[0]), L.ptr(pri[1]), L.ptr(pri[2]),
-                                 B, H, W, (0 if mode == "sot" else 1) | (2 if raw else 0), L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
-                                 L.stream_ptr()), "uni_head")
+            mf = empty_nhwc(8, H // 8, W // 8, dev, Bi)                 # mask branch outputs depend on the image only
+            um = empty_nhwc(9 * m.up_rate ** 2, H // 8, W // 8, dev, Bi)
+        fn = L.lib().uni_head_objects if objects else L.lib().uni_head
+        L.check(fn(m._ctx, L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(pri[0]), L.ptr(pri[1]), L.ptr(pri[2]),
+                   B, H, W, (0 if mode == "sot" else 1) | (2 if raw else 0), L.ptr(out), L.ptr(dyn), L.ptr(mf), L.ptr(um),
+                   L.stream_ptr()), "uni_head_objects" if objects else "uni_head")
         self.hw = [tuple(x.shape[2:]) for x in f]
         return out, dyn, mf, um
 

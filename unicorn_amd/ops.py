@@ -165,3 +165,76 @@ def letterbox(image, input_size, swap_rb=True, device=None):
         L.check(L.lib().uni_letterbox(L.ptr(image), image.shape[0], image.shape[1], int(bool(swap_rb)), H, W, L.ptr(out), C.byref(r),
                                       L.stream_ptr()), "uni_letterbox")
     return out, r.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mask post-processing of the VOS / MOTS drivers on the device (csrc/mask_post.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def mask_resize(masks, r, H, W, thr=None):
+    """masks (N, Hn, Wn) fp32 cuda -> F.interpolate(masks[:, None], scale_factor=1/r, bilinear)[:, 0, :H, :W] pasted into zero
+    (N, H, W) maps (unicorn_vos.py:146-150); with thr: the `> thr` byte masks of mot_evaluator.py:803-804 instead."""
+    _need_cuda(masks)
+    m = masks.float().contiguous()
+    N, Hn, Wn = m.shape
+    if N == 0:
+        return torch.empty((0, H, W), device=m.device, dtype=torch.float32 if thr is None else torch.uint8)
+    if thr is None:
+        out = torch.empty((N, H, W), device=m.device, dtype=torch.float32)
+        L.check(L.lib().uni_mask_resize(L.ptr(m), N, Hn, Wn, float(r), H, W, 0.0, L.ptr(out), None, L.stream_ptr()), "uni_mask_resize")
+    else:
+        out = torch.empty((N, H, W), device=m.device, dtype=torch.uint8)
+        L.check(L.lib().uni_mask_resize(L.ptr(m), N, Hn, Wn, float(r), H, W, float(thr), None, L.ptr(out), L.stream_ptr()), "uni_mask_resize")
+    return out
+
+
+def vos_merge(probs, prob_ids, r, H, W, init_masks=None, init_ids=()):
+    """soft aggregation of unicorn_vos.py:99-121 fused with the 1/r resize: probs (K1, Hn, Wn) network-resolution mask
+    probabilities of the tracked objects (ids prob_ids, cur_obj_ids order), init_masks (K2, H, W) of objects introduced in
+    this frame -> (H, W) uint8 id map on the device."""
+    dev = probs.device if probs is not None else init_masks.device
+    K1 = 0 if probs is None else probs.shape[0]
+    K2 = len(init_ids)
+    out = torch.empty((H, W), device=dev, dtype=torch.uint8)
+    p = probs.float().contiguous() if K1 else None
+    pid = torch.tensor([int(k) for k in prob_ids], dtype=torch.int32, device=dev) if K1 else None
+    im = init_masks.to(torch.uint8).contiguous() if K2 else None
+    iid = torch.tensor([int(k) for k in init_ids], dtype=torch.int32, device=dev) if K2 else None
+    Hn, Wn = (p.shape[1], p.shape[2]) if K1 else (0, 0)
+    L.check(L.lib().uni_vos_merge(L.ptr(p), L.ptr(pid), K1, Hn, Wn, float(r), L.ptr(im), L.ptr(iid), K2, H, W, L.ptr(out),
+                                  L.stream_ptr()), "uni_vos_merge")
+    return out
+
+
+def mots_overlap_free(masks):
+    """mot_evaluator.py:852-859: (N, H, W) bool/uint8 masks in track order -> earlier tracks keep overlapping pixels"""
+    _need_cuda(masks)
+    m = masks.to(torch.uint8).contiguous()
+    out = torch.empty_like(m)
+    if m.shape[0]:
+        L.check(L.lib().uni_mots_overlap_free(L.ptr(m), m.shape[0], m.shape[1], m.shape[2], L.ptr(out), L.stream_ptr()), "uni_mots_overlap_free")
+    return out
+
+
+def rle_encode(masks, max_runs=1 << 14):
+    """pycocotools.mask.encode(np.asfortranarray(mask))["counts"] for every (H, W) mask of an (N, H, W) {0,1} cuda tensor
+    (mot_evaluator.py:884-890) -> list of bytes objects.  Runs are found and the strings are written on the device; one
+    read-back of lengths + chars."""
+    _need_cuda(masks)
+    m = masks.to(torch.uint8).contiguous()
+    N, H, W = m.shape
+    if N == 0:
+        return []
+    while True:
+        max_chars = 6 * (max_runs + 1)
+        ws = torch.empty(L.lib().uni_rle_workspace_bytes(N, H, W, max_runs), device=m.device, dtype=torch.uint8)
+        chars = torch.empty((N, max_chars), device=m.device, dtype=torch.uint8)
+        lens = torch.empty((N,), device=m.device, dtype=torch.int32)
+        L.check(L.lib().uni_rle_encode(L.ptr(m), N, H, W, max_runs, max_chars, L.ptr(chars), L.ptr(lens), None, None, L.ptr(ws),
+                                       ws.numel(), L.stream_ptr()), "uni_rle_encode")
+        ln = lens.cpu().tolist()
+        if min(ln) >= 0:
+            break
+        max_runs *= 4                      # a mask with more runs than expected: retry with larger bounds
+    top = max(ln)
+    host = chars[:, :top].cpu().numpy()
+    return [host[i, :ln[i]].tobytes() for i in range(N)]

@@ -38,6 +38,45 @@ def gather_result_rows(rows, group=None):
     return _sort(torch.cat([o[:c] for o, c in zip(out, counts)], 0))
 
 
+def gather_byte_strings(items, group=None):
+    """Variable-length gather (mask RLE bytes travel next to the fixed-stride rows; replaces the pickled gather of
+    unicorn/utils/dist.py:224-265).  items: list of bytes objects of this rank (e.g. RLE "counts" strings, one per result row).
+    Returns, on every rank, the list of per-rank lists in rank order.  Three collectives, no pickling: item counts, item
+    lengths (padded to the max count), payload bytes (padded to the max total)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [list(items)]
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    n = torch.tensor([len(items)], device=dev, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    lens = torch.zeros((mx,), device=dev, dtype=torch.int64)
+    if items:
+        lens[:len(items)] = torch.tensor([len(b) for b in items], dtype=torch.int64)
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens, group=group)
+    totals = [int(l[:c].sum().item()) for l, c in zip(all_lens, counts)]
+    mt = max(max(totals), 1)
+    payload = torch.zeros((mt,), device=dev, dtype=torch.uint8)
+    if items and totals[dist.get_rank(group)]:
+        blob = b"".join(items)
+        payload[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    all_pay = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(all_pay, payload, group=group)
+    out = []
+    for r in range(world):
+        buf = all_pay[r][:totals[r]].cpu().numpy().tobytes()
+        ls = all_lens[r][:counts[r]].cpu().tolist()
+        pos, cur = 0, []
+        for l in ls:
+            cur.append(buf[pos:pos + l])
+            pos += l
+        out.append(cur)
+    return out
+
+
 def _sort(rows):
     if rows.shape[0] == 0:
         return rows

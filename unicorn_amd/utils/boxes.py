@@ -77,7 +77,8 @@ def postprocess_inst(prediction, locations, dynamic_params, fpn_levels, mask_fea
         # fused DynamicMaskHead + aligned_bilinear(d_rate) (boxes.py:138-146) on the surviving anchors
         lv = fpn_levels[i]
         lv = lv[idx if lv.is_cuda else idx.cpu()]                  # the reference keeps fpn_levels on the CPU (unicorn_head_mask.py:519)
-        masks = condinst_masks(mask_feats[i:i + 1], um, dynamic_params[i][idx], locations[idx], lv, mask_head.up_rate, d_rate)
+        mf = mask_feats[0:1] if len(mask_feats) == 1 else mask_feats[i:i + 1]     # object-batched head: one image, K prediction sets
+        masks = condinst_masks(mf, um, dynamic_params[i][idx], locations[idx], lv, mask_head.up_rate, d_rate)
         output.append(det)
         output_mask.append(masks)
     return output, output_mask
