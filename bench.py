@@ -26,6 +26,10 @@ import subprocess
 import sys
 import time
 
+# torch's OpenMP team spin-waits after every parallel CPU region; inside a CPU-quota'd container those spinning threads can
+# exhaust the quota and freeze the HIP dispatch thread for tens of ms (measured: periodic 45 ms GPU-idle gaps).  The timed
+# path has no large CPU tensor ops, and the oracle leg is bracketed by set_num_threads; passive waiting removes the rest.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -318,6 +322,7 @@ def main():
                     ea, eb = r["e_cur"].cpu().flatten(2)[0].double(), o["embed_cur"].flatten(2)[0].double()
                     coss.append((ea * eb).sum(0) / (ea.norm(dim=0) * eb.norm(dim=0)).clamp_min(1e-30))
                     prs.append(float((r["coarse"].cpu().reshape(-1) - o["coarse"].reshape(-1)).abs().max()))
+        torch.set_num_threads(1)           # the remaining legs are GPU work: no OpenMP team next to the HIP dispatch thread
         cpu = {"value": round(args.cpu_frames / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames of the same %s %s step at %dx%d, fp32, torch CPU (oracle/unicorn_oracle.py)"
                          % (args.cpu_frames, args.model, args.task, H, W)}
@@ -379,6 +384,7 @@ def main():
                 torch.set_num_threads(min(os.cpu_count() or 1, 16))
                 st = uo.vos_init(vs.P, vs.cfg, vs.frames[0].cpu(), vs.vos_boxes)
                 exp = uo.vos_step(vs.P, vs.cfg, st, vs.frames[1].cpu())
+                torch.set_num_threads(1)
             mi, bi = [], []
             for k in vs.vos_boxes:
                 d_o, m_o = exp[k]

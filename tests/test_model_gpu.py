@@ -356,6 +356,46 @@ def test_large_mask_vos_k3_tracker_step_vs_oracle():
     assert met["box_iou_min"] > 0.999 and met["mask_iou_min"] > 0.999, met
 
 
+def test_vos_tracker_reference_groups_raw_images_vs_oracle():
+    """Row N3a + N1: the full driver on RAW uint8 frames (letterbox r != 1, so the resize of the aggregation is exercised),
+    with an object that APPEARS AT FRAME 2 (info["init_object_ids"] / init_bbox / init_mask, unicorn_vos.py:87-98): from frame 3
+    on it is tracked against its own reference frame.  HIP tracker vs oracle.vos_track_frame, frame by frame."""
+    import letterbox_oracle as lo
+    from unicorn_amd.tracker import UnicornVOSTrack
+    m, cfg, P = build("unicorn_track_tiny_mask", "f16x2")
+    h, w, size = 240, 400, (320, 512)
+    g = np.random.default_rng(7)
+    base = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    imgs = [np.roll(base, (2 * t, 3 * t), (0, 1)) for t in range(4)]
+    b0 = {"1": [60.0, 40.0, 120.0, 90.0], "2": [230.0, 110.0, 100.0, 80.0]}              # xywh on the original image
+    new = {"3": [20.0, 150.0, 90.0, 70.0]}
+    init_mask = np.zeros((h, w), dtype=np.uint8)
+    init_mask[150:220, 20:110] = 3
+    trk = UnicornVOSTrack(m, input_size=size, d_rate=cfg.d_rate)
+    trk.initialize(imgs[0], {"init_object_ids": list(b0), "init_bbox": b0})
+    xyxy = lambda b: torch.tensor([b[0], b[1], b[0] + b[2], b[1] + b[3]])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0, r = lo.letterbox(imgs[0], size, True)
+    with torch.no_grad():
+        st = uo.vos_track_init(P, cfg, torch.from_numpy(t0)[None], {k: xyxy(b) for k, b in b0.items()}, (h, w), r)
+    agree = []
+    for t in (1, 2, 3):
+        info = {"init_object_ids": list(new), "init_bbox": new, "init_mask": init_mask} if t == 2 else {}
+        seg = trk.track(imgs[t], dict(info))["segmentation"]
+        tt, r = lo.letterbox(imgs[t], size, True)
+        oinfo = {"init_object_ids": list(new), "init_bbox": {k: xyxy(b) for k, b in new.items()}, "init_mask": init_mask} if t == 2 else {}
+        with torch.no_grad():
+            exp = uo.vos_track_frame(P, cfg, st, torch.from_numpy(tt)[None], oinfo, r)
+        assert seg.shape == exp.shape == (h, w) and seg.dtype == np.uint8
+        agree.append(float((seg == exp).mean()))
+        if t == 2:
+            assert (seg[init_mask == 3] == 3).mean() > 0.9             # the given mask of the new object (ties with a saturated p = 1 of a lower id aside)
+    METRICS["vos_reference_groups_agreement"] = agree
+    _dump()
+    assert len(trk.obj_ids_new) == 1 and trk.obj_ids_new[0] == ["3"] and len(st["groups"]) == 2
+    assert min(agree) > 0.999, agree                                   # id maps agree (fp32-grade masks; ties at mask borders aside)
+
+
 def test_whole_mot_mode_matches_head_with_zero_priors():
     m, cfg, P = build("unicorn_track_tiny", "fp32")
     frames, _ = synth.synth_clip(320, 320, 2, seed=1)

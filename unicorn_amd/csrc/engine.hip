@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 // ------------------------------------------------------------------------------------------------
@@ -710,7 +711,8 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     }
     // The three FPN levels are independent until the decode: run them concurrently (the stride-16/32 levels are
     // far too small to fill 256 CUs on their own).  Level k gets its own stream and a disjoint workspace slice.
-    const bool fork = c->aux[0] && c->aux[1] && !c->prof_on;   // serialised while event-profiling so per-kernel times are not inflated by overlap
+    static const bool no_fork = getenv("UNI_NO_FORK") != nullptr;     // A/B switch
+    const bool fork = c->aux[0] && c->aux[1] && !c->prof_on && !no_fork;   // serialised while event-profiling so per-kernel times are not inflated by overlap
     hipStream_t s_main = s;
     if (fork) {
         UNI_CHECK_HIP(hipEventRecord(c->ev_fork, s_main));

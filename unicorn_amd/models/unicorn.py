@@ -114,13 +114,19 @@ class UnicornHeadMask(UnicornHead):
     def __init__(self, model):
         super().__init__(model)
         self.mask_head = DynamicMaskHead(model.up_rate)
+        self._levels_cache = {}
 
     def forward(self, xin, mask_in, mode=None):
         out, dyn, mf, um = self._run(xin, mask_in, mode)
         grids, strides = self._m._grids(self.hw, out.device)
         locations = ((grids + 0.5) * strides)[0]                               # unicorn_head_mask.py:518
-        levels = torch.cat([torch.full((out.shape[0], h * w), k) for k, (h, w) in enumerate(self.hw)], 1)   # CPU like the reference
-        return out, locations, dyn, levels, mf, um
+        # fpn_levels live on the CPU like the reference's (unicorn_head_mask.py:519); they depend on the shapes only, so they are
+        # built once: a (K, 21000) torch.full / cat per call is large enough to wake torch's OpenMP team, whose spin-waiting
+        # threads can exhaust a container's CPU quota and freeze the HIP dispatch thread for tens of ms (seen as periodic stalls)
+        key = (out.shape[0], tuple(self.hw))
+        if key not in self._levels_cache:
+            self._levels_cache[key] = torch.cat([torch.full((out.shape[0], h * w), k) for k, (h, w) in enumerate(self.hw)], 1)
+        return out, locations, dyn, self._levels_cache[key], mf, um
 
 
 class Unicorn:
