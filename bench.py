@@ -47,8 +47,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--batch", type=int, default=16, help="frames of the stream processed per step (time-batched: the SOT step of a "
                     "frame depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
-    ap.add_argument("--corr-precision", type=int, default=1, choices=[0, 1],
-                    help="0 = fp32 MFMA correlation, 1 = fp32-equivalent bf16x3 split (default)")
+    ap.add_argument("--corr-precision", type=int, default=2, choices=[0, 1, 2],
+                    help="0 = fp32 MFMA correlation, 1 = fp32-equivalent bf16x3 split, 2 = fp32-equivalent f16x2 split (default)")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline AND in-run parity)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (no modes / configs sub-results)")
@@ -288,10 +288,11 @@ def main():
                 torch.cuda.synchronize()
             ms = ev[0].elapsed_time(ev[1]) / 5
             n = a.shape[1]
-            # precision 1 issues 6 bf16 MFMA terms per fp32-equivalent product: effective peak = 2500 / 6 TFLOP/s
+            # precision 1 / 2 issue 6 / 3 MFMA terms per fp32-equivalent product: effective peak = 2500 / 6 or 2500 / 3 TFLOP/s
             extra["corr_fp32"] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * n * n * 128 / (ms * 1e-3) / 1e12, 2),
-                                  "peak_effective": 157.3 if args.corr_precision == 0 else round(2500.0 / 6, 1),
-                                  "mode": "fp32 MFMA" if args.corr_precision == 0 else "bf16x3 split (6 exact partial products, fp32 accumulate)"}
+                                  "peak_effective": [157.3, round(2500.0 / 6, 1), round(2500.0 / 3, 1)][args.corr_precision],
+                                  "mode": ["fp32 MFMA", "bf16x3 split (6 exact partial products, fp32 accumulate)",
+                                           "f16x2 split (3 partial products, fp32 accumulate)"][args.corr_precision]}
 
     # ---------------- CPU baseline (the oracle = port of the reference, host cores, bounded sample) + in-run parity ----------------
     cpu, parity = None, None
@@ -413,7 +414,8 @@ def main():
                                    "head); one independent stream per GPU, %d consecutive frames per step" % (args.model, args.task.upper(), H, W, nf),
                        "model": args.model, "task": args.task, "precision": args.precision, "frames_per_step": nf, "streams": world,
                        "weights": "synthetic (oracle/synth.py)",
-                       "corr_dtype": "f32" if args.corr_precision == 0 else "f32-equivalent (bf16x3 split operands, fp32 accumulate)", "accum": "f32"},
+                       "corr_dtype": ["f32", "f32-equivalent (bf16x3 split operands, fp32 accumulate)",
+                                      "f32-equivalent (f16x2 split operands, fp32 accumulate)"][args.corr_precision], "accum": "f32"},
             "parity": parity, "roofline": roof, "cpu_baseline": cpu, "modes": modes, "configs": configs, "kernels": extra,
         }
         print(json.dumps(line))

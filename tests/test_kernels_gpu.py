@@ -259,7 +259,7 @@ def test_msda_random_vs_oracle(L):
     assert out0.shape == (1, 0, 256)
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("R,Q,K", [(1600, 1600, 1), (1000, 1300, 3), (4000, 2000, 5), (333, 257, 9)])
 def test_corr_softmax_pv(L, R, Q, K, prec):
     from unicorn_amd.ops import corr_softmax_pv
@@ -284,12 +284,15 @@ def test_corr_split_matches_fp32_mfma(L):
     v = torch.rand(3, R, generator=g).cuda()
     o0 = corr_softmax_pv(er, ec, v, precision=0)
     o1 = corr_softmax_pv(er, ec, v, precision=1)
+    o2 = corr_softmax_pv(er, ec, v, precision=2)     # f16x2 split: 3 products per slice
     qs = torch.arange(0, Q, 97, device="cuda")
     ref = (v.double() @ torch.softmax(er.double().t() @ ec[:, qs].double(), 0)).float()
     e0 = (o0[:, qs] - ref).abs().max().item()
     e1 = (o1[:, qs] - ref).abs().max().item()
-    assert (o0 - o1).abs().max().item() < 2e-5
+    e2 = (o2[:, qs] - ref).abs().max().item()
+    assert (o0 - o1).abs().max().item() < 2e-5 and (o0 - o2).abs().max().item() < 2e-5
     assert e1 < max(3 * e0, 2e-6), (e0, e1)     # same error class as the fp32 MFMA path
+    assert e2 < max(4 * e0, 3e-6), (e0, e2)     # 22 operand bits instead of 24
 
 
 def test_corr_spiked_rescale(L):
@@ -303,7 +306,7 @@ def test_corr_spiked_rescale(L):
     er[:, 5] = ec[:, 100] * 40           # and at the first tile for query 100
     v = torch.rand(2, R, generator=g)
     ref = uo.correlation_propagate(er, ec, v)
-    for prec in (0, 1):
+    for prec in (0, 1, 2):
         out = corr_softmax_pv(er.cuda(), ec.cuda(), v.cuda(), precision=prec).cpu()
         assert (out - ref).abs().max() < 2e-5
         assert abs(out[0, 7] - v[0, 1900]) < 1e-4 and abs(out[1, 100] - v[1, 5]) < 1e-4
@@ -658,3 +661,22 @@ def test_mots_overlap_free_and_rle_device(L):
     assert rle_encode(of[:0]) == []
     dense = (g.random((2, 64, 96)) < 0.5).astype(np.uint8)                      # > max_runs runs: the wrapper retries with larger bounds
     assert rle_encode(torch.from_numpy(dense).cuda(), max_runs=64) == [mo.mask_to_rle_string(m) for m in dense]
+
+
+def test_mots_mask_pipeline_device(L):
+    """mot_evaluator.py:803-804 + :850-863 + :884-890 composed (unicorn_amd/utils/masks.py) vs the oracle composition"""
+    from unicorn_amd.utils.masks import mots_rle, mots_threshold
+    g = torch.Generator().manual_seed(9)
+    Hn, Wn, scale, h, w = 100, 160, 0.74, 130, 210
+    score = torch.rand(5, 1, Hn, Wn, generator=g)
+    score[2, 0, 20:70, 30:120] = 0.9
+    score[0, 0, 40:90, 60:150] = 0.8
+    m_dev = mots_threshold(score.cuda(), scale, h, w, 0.30)
+    m_ref = (mo.resize_bilinear(score[:, 0].numpy(), scale, h, w) > np.float32(0.30)).astype(np.uint8)
+    assert np.array_equal(m_dev.cpu().numpy(), m_ref)
+    order = [3, 0, 2]                                                  # association kept 3 of 5, ascending track id order
+    free, strs = mots_rle(m_dev, order)
+    ref_free = mo.overlap_free(m_ref[order])
+    assert np.array_equal(free.cpu().numpy(), ref_free)
+    assert strs == [mo.mask_to_rle_string(m).decode("utf-8") for m in ref_free]
+    assert mots_rle(m_dev[:0])[1] == [] and mots_threshold(score[:0].cuda(), scale, h, w).shape == (0, h, w)

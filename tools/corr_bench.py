@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from unicorn_amd.ops import corr_softmax_pv
 a = torch.randn(128, 16000, device="cuda") * 0.5; b = torch.randn(128, 16000, device="cuda") * 0.5; v = torch.rand(1, 16000, device="cuda")
-for prec in (0, 1):
+for prec in (0, 1, 2):
     for _ in range(3): corr_softmax_pv(a, b, v, precision=prec)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

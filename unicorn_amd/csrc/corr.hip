@@ -334,6 +334,169 @@ __global__ __launch_bounds__(64 * NWV) void corr_split_kernel(const float* __res
     }
 }
 
+// ---- precision 2: fp32-equivalent contraction on the f16 MFMA pipe ("f16x2", the operand format of the f16x2 model precision):
+// x = h + l with h = f16(x), l = f16(x - h) (22 significand bits; embeddings are O(1..100), far inside the f16 range; values below
+// 2^-14 keep an ABSOLUTE error of 2^-25).  Three products h.h, h.l, l.h per 16-deep slice (v_mfma_f32_32x32x16_f16, fp32
+// accumulate) instead of the six of the bf16x3 split: half the MFMA time at the same error class (the dropped l.l term is
+// <= 2^-22 relative).  Same structure as corr_split_kernel; LDS = 2 planes [32 rows][128 dims] f16 per buffer.
+__device__ __forceinline__ void split2h(const float (&x)[8], f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f16 hh, ll;
+        h2_split(x[e], hh, ll);
+        h[e] = hh; l[e] = ll;
+    }
+}
+
+template <int KV, int NWV>
+__global__ __launch_bounds__(64 * NWV) void corr_h2_kernel(const float* __restrict__ eref, const float* __restrict__ ecur,
+                                                      const float* __restrict__ v, float* __restrict__ out,
+                                                      float* __restrict__ ws, int R, int Q, int K, int nsplit,
+                                                      int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PLANE = TR * CD;                       // f16 elements per piece plane (32 x 128)
+    f16* As = reinterpret_cast<f16*>(smem);              // [2 buffers][2 planes][TR][CD]
+    float* Vs = smem + (2 * 2 * PLANE) / 2;              // [2][KV*TR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int split = blockIdx.y;
+    const int q = blockIdx.x * (32 * NWV) + wave * 32 + fr;
+    const int qc = q < Q ? q : Q - 1;
+
+    f16x8 qh[8], ql[8];                                  // stationary operand: slice c = dims 16c + 8 fh + (0..7), log2 domain
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(ecur + (size_t)qc * CD + 16 * c + 8 * fh);
+        const f32x4 t0 = src[0], t1 = src[1];
+        constexpr float L2E = 1.4426950408889634f;
+        const float x[8] = {t0[0] * L2E, t0[1] * L2E, t0[2] * L2E, t0[3] * L2E, t1[0] * L2E, t1[1] * L2E, t1[2] * L2E, t1[3] * L2E};
+        split2h(x, qh[c], ql[c]);
+    }
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+    const int ntiles = (r_end - r_begin + TR - 1) / TR;
+
+    constexpr int SPT = 512 / (64 * NWV);
+    f32x4 g0[SPT], g1[SPT];
+    float gv;
+    auto gload = [&](int t) __attribute__((always_inline)) {
+        const int r0 = r_begin + t * TR;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int ch = tid + 64 * NWV * j;
+            const int row = min(r0 + (ch >> 4), R - 1);
+            const f32x4* src = reinterpret_cast<const f32x4*>(eref + (size_t)row * CD + (ch & 15) * 8);
+            g0[j] = src[0]; g1[j] = src[1];
+        }
+        const int k = tid >> 5, r = r0 + (tid & 31);
+        gv = (k < K && k < KV && r < R) ? v[(size_t)k * R + r] : 0.f;
+    };
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int ch = tid + 64 * NWV * j, srow = ch >> 4, sch = ch & 15;
+            const float x[8] = {g0[j][0], g0[j][1], g0[j][2], g0[j][3], g1[j][0], g1[j][1], g1[j][2], g1[j][3]};
+            f16x8 h, l;
+            split2h(x, h, l);
+            f16* dst = As + buf * 2 * PLANE + srow * CD + ((sch ^ (srow & 15)) << 3);
+            *reinterpret_cast<f16x8*>(dst) = h;
+            *reinterpret_cast<f16x8*>(dst + PLANE) = l;
+        }
+        if (tid < KV * TR) Vs[buf * KV * TR + tid] = gv;
+    };
+
+    float m = -INFINITY, l = 0.f, o[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) o[k] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        const f16* arow = As + buf * 2 * PLANE + fr * CD;
+        f32x16 acc, acc2;                                  // two independent chains (leading / cross terms)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int off = ((2 * c + fh) ^ (fr & 15)) << 3;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + off);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(arow + PLANE + off);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+        const int r0 = r_begin + t * TR;
+        float sc[16], tmax = -INFINITY;
+        if (r0 + TR <= r_end) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = acc[r]; tmax = fmaxf(tmax, sc[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = (r0 + rowof(r, fh) < r_end) ? acc[r] : -INFINITY;
+                tmax = fmaxf(tmax, sc[r]);
+            }
+        }
+        const float mn = fmaxf(m, tmax);
+        if (mn > -INFINITY) {
+            const float f = (m > -INFINITY) ? __builtin_amdgcn_exp2f(m - mn) : 0.f;
+            l *= f;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) o[k] *= f;
+            const float* vt = Vs + buf * KV * TR;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float pr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pr[j] = __builtin_amdgcn_exp2f(sc[4 * g + j] - mn);
+                    l += pr[j];
+                }
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(vt + k * TR + 8 * g + 4 * fh);
+                    o[k] += pr[0] * v4[0] + pr[1] * v4[1] + pr[2] * v4[2] + pr[3] * v4[3];
+                }
+            }
+            m = mn;
+        }
+        if (t + 1 < ntiles) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    m *= 0.6931471805599453f;
+    {
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        const float M = fmaxf(m, m2);
+        const float f1 = (m > -INFINITY) ? __expf(m - M) : 0.f;
+        const float f2 = (m2 > -INFINITY) ? __expf(m2 - M) : 0.f;
+        l = l * f1 + l2 * f2;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const float o2 = __shfl_xor(o[k], 32, 64);
+            o[k] = o[k] * f1 + o2 * f2;
+        }
+        m = M;
+    }
+    if (fh == 0 && q < Q) {
+        if (nsplit == 1) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k)
+                if (k < K) out[(size_t)k * Q + q] = o[k] / l;
+        } else {
+            float* w = ws + ((size_t)split * Q + q) * (2 + KV);
+            w[0] = m;
+            w[1] = l;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) w[2 + k] = o[k];
+        }
+    }
+}
+
 template <int KV>
 __global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int Q, int K, int nsplit) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,7 +557,11 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
     const int ns = pick_nsplit(R, Q, precision);
     int rps = cdiv(cdiv(R, ns), TR) * TR;
     const int ns_eff = cdiv(R, rps);   // every split non-empty
-    if (precision) {
+    if (precision == 2) {
+        size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
+        hipLaunchKernelGGL((corr_h2_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
+                           Q, K, ns_eff, rps);
+    } else if (precision) {
         size_t lds = (size_t)2 * 3 * TR * CD * sizeof(bf16) + (size_t)2 * KV * TR * sizeof(float);
         hipLaunchKernelGGL((corr_split_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
                            Q, K, ns_eff, rps);
@@ -419,7 +586,7 @@ int launch_corr(const float* eref, const float* ecur, const float* v, float* out
                 int precision, void* workspace, size_t ws_bytes, hipStream_t s) {
     UNI_REQUIRE(D == CD, "corr: embedding dim %d unsupported (128)", D);
     UNI_REQUIRE(R > 0 && Q > 0 && K > 0, "corr: empty problem R=%d Q=%d K=%d", R, Q, K);
-    UNI_REQUIRE(precision == 0 || precision == 1, "corr: precision %d not implemented (0 = fp32 MFMA, 1 = bf16x3 split)", precision);
+    UNI_REQUIRE(precision >= 0 && precision <= 2, "corr: precision %d not implemented (0 = fp32 MFMA, 1 = bf16x3 split, 2 = f16x2 split)", precision);
     UNI_REQUIRE(ws_bytes >= corr_workspace_bytes(R, Q, K), "corr: workspace too small");
     UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
     float* ws = reinterpret_cast<float*>(workspace);

@@ -50,7 +50,7 @@ class UnicornSOTTrack:
             e_pre = self.model(feat=f_pre, mode="upsample")
             e_cur = self.model(feat=f_cur, mode="upsample")
             pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), self.lbs_pre,
-                                   precision=0 if getattr(self.model, "precision", "bf16") == "fp32" else 1)
+                                   precision=0 if getattr(self.model, "precision", "bf16") == "fp32" else 2)
             coarse = pred.view(1, -1, self.dh, self.dw)
             outputs = self.model.head(fpn, prior_pyramid(coarse), mode="sot")
             outputs = outputs[0] if isinstance(outputs, tuple) else outputs

@@ -72,7 +72,7 @@ class UnicornVOSTrack:
             e_pre = m(feat=f_pre, mode="upsample")
             e_cur = m(feat=f_cur, mode="upsample")
             values = torch.cat([self.lbs_pre_dict[k] for k in object_ids], 0)                 # (K, HW/64): ONE correlation call
-            prec = 0 if getattr(m, "precision", "bf16") == "fp32" else 1
+            prec = 0 if getattr(m, "precision", "bf16") == "fp32" else 2       # fp32 MFMA in the exact mode, f16x2 split otherwise
             pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), values, precision=prec)
             K = len(object_ids)
             p8, p16, p32 = prior_pyramid(pred.view(1, K, self.dh, self.dw))                   # (1,K,..) pyramid of all objects

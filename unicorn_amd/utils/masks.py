@@ -1,0 +1,32 @@
+"""Mask post-processing of the MOTS evaluator (unicorn/evaluators/mot_evaluator.py:803-890) on the device (row N1).
+
+    masks = F.interpolate(outputs_mask[0], scale_factor=1/scale, bilinear)[:, 0, :img_h, :img_w] > mask_thres     (:803-804)
+    ... association picks / reorders the masks (indexs, valid_inds, ascending track id)                              (:843-856)
+    overlap-free: masks_new[n] = masks[n] & ~(masks[0] | ... | masks[n-1])                                          (:857-863)
+    rle = pycocotools.mask.encode(np.asfortranarray(mask))["counts"].decode("utf-8")                                (:884-890)
+
+`mots_threshold` and `mots_rle` wrap the three kernels (uni_mask_resize, uni_mots_overlap_free, uni_rle_encode); only the RLE
+strings (a few KB) leave the device.
+"""
+import torch
+
+from ..ops import mask_resize, mots_overlap_free, rle_encode
+
+
+def mots_threshold(outputs_mask, scale, img_h, img_w, mask_thres=0.30):
+    """outputs_mask (N, 1, Hn, Wn) sigmoid scores of postprocess_inst -> (N, img_h, img_w) uint8 masks (mot_evaluator.py:803-804)"""
+    if outputs_mask is None or outputs_mask.shape[0] == 0:
+        dev = outputs_mask.device if outputs_mask is not None else "cuda"
+        return torch.zeros((0, img_h, img_w), dtype=torch.uint8, device=dev)
+    return mask_resize(outputs_mask[:, 0], scale, int(img_h), int(img_w), thr=mask_thres)
+
+
+def mots_rle(masks, order=None):
+    """masks (N, H, W) uint8 in detection order, order: indices into masks in ascending-track-id order (after `indexs` /
+    `valid_inds`, mot_evaluator.py:850-856).  Returns (overlap-free masks (M, H, W) uint8 on the device, list of M RLE strings)."""
+    if order is not None:
+        masks = masks[torch.as_tensor(order, dtype=torch.long, device=masks.device)]
+    if masks.shape[0] == 0:
+        return masks, []
+    free = mots_overlap_free(masks)
+    return free, [b.decode("utf-8") for b in rle_encode(free)]
