@@ -207,6 +207,11 @@ int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta
                   uint16_t* outB, uni_stream_t stream);
 int uni_dwconv7_ln(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta,
                    float eps, int H, int W, int C, uint16_t* out_bf16, uni_stream_t stream);
+/* LDS-tiled depthwise 7x7 (+bias) with the LayerNorm split off (convnext.py:43-47): raw conv output in operand format `fmt`
+ * (0 bf16, 1 fp32, 2 f16x2) and per-pixel stats (B*H*W, 2) = (mean, rstd) of LN over C; the engine folds the LayerNorm into the
+ * pwconv1 epilogue.  C % 32 == 0. */
+int uni_dwconv7_raw(const float* x_nhwc, const float* w49c, const float* bias, float eps, int B, int H, int W, int C, int fmt,
+                    void* out, float* stats, uni_stream_t stream);
 int uni_groupnorm_act(const float* x, const double* stats, const float* gamma, const float* beta, float eps, int M,
                       int C, int G, int act, float* outF, uint16_t* outB, uni_stream_t stream);
 int uni_stem(const float* img, int H, int W, const float* w48c, const float* bias, const float* gamma,

@@ -580,3 +580,16 @@ def test_raw_outputs_decode_in_inference_false():
     mm.head.decode_in_inference = False
     with pytest.raises(ValueError):
         mm.head(fpn, pri, mode="mot")
+
+
+def test_layernorm_folded_into_pwconv1_optional_path():
+    """UNI_DW_RAW=1 (read when the weights are packed): LDS-tiled raw depthwise conv + per-pixel statistics, LayerNorm folded into the
+    pwconv1 epilogue (csrc/dwconv.hip, GemmArgs::rowstat).  Off by default (not faster, DESIGN.md §4) but kept exact: the golden
+    parity tests must pass with it, for both 16-bit operand formats."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UNI_DW_RAW="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_tiny_320_vs_reference_golden and unicorn_track_tiny_mask and not fp32"], env=env, capture_output=True, text=True,
+                       cwd=ROOT, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]

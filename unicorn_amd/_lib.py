@@ -62,6 +62,7 @@ PROTOS = {
     "uni_cast_h2": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, C.c_void_p]),
     "uni_layernorm": (c_i, [c_f, c_i, c_f, c_f, C.c_float, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_dwconv7_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_f, C.c_void_p]),
+    "uni_dwconv7_raw": (c_i, [c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_groupnorm_act": (c_i, [c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_stem": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, C.c_void_p]),
 }

@@ -254,6 +254,7 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
         else if (conv) cfg = b12 >= 400 ? 12 : 11;
         else cfg = b21 >= 400 ? 21 : 11;
     }
+    if (a.rowstat) UNI_REQUIRE(a.epi, "gemm(h2): rowstat needs the vector-aligned (staged) epilogue");
     if (!a.epi && (cfg == 44 || cfg == 48 || cfg == 42)) cfg = 22;
     // plain GEMMs that take the 256 x 256 tile go to the persistent variant (gemm_h2p.hip); 144 forces it
     if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_h2p_supported(a) && !getenv("UNI_NO_H2P")) cfg = 144;

@@ -173,6 +173,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2p_kernel(GemmArgs p) {
         const float ws = p.wscale;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float rs_mean = 0.f, rs_rstd = 1.f;       // LayerNorm of the A row folded in (GemmArgs::rowstat): rstd * (acc - mean * colsum) + bias
+            if (p.rowstat) {
+                const int row = rb0 + i * 32 + fr;
+                const float2 st2 = *reinterpret_cast<const float2*>(p.rowstat + 2 * (size_t)(row < p.M ? row : p.M - 1));
+                rs_mean = st2.x; rs_rstd = st2.y;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // fp32 [32 rows][32 cols] of block (i, j): 128-B rows, float4 chunks XOR-swizzled with row & 7
@@ -181,8 +187,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2p_kernel(GemmArgs p) {
                     const int col = nw0 + j * 32 + 8 * g + 4 * fh;
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
                     f32x4 v;
+                    if (p.rowstat) {
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.colsum + (col < p.N ? col : 0));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(acc[i][j][4 * g + e], ws, b4[e]));
+                        for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(rs_rstd, fmaf(-rs_mean, cs[e], acc[i][j][4 * g + e] * ws), b4[e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(acc[i][j][4 * g + e], ws, b4[e]));
+                    }
                     *reinterpret_cast<f32x4*>(st + fr * 128 + (((2 * g + fh) ^ (fr & 7)) << 4)) = v;
                 }
                 wave_fence();
