@@ -568,7 +568,7 @@ def test_wrapper_error_paths_raise_unicorn_error(L):
         letterbox(torch.zeros(8, 8, 3, device="cuda", dtype=torch.float32), (32, 32))
 
 
-@pytest.mark.parametrize("cfg", [144, 44, 48, 0])
+@pytest.mark.parametrize("cfg", [188, 144, 44, 48, 0])
 @pytest.mark.parametrize("case", [
     # (M, N, K, act, res, outF, outB): several tiles per persistent block
     (70001, 256, 64, 2, False, False, True),      # two K steps per tile, GELU, operand-format out, ragged M
@@ -578,7 +578,10 @@ def test_wrapper_error_paths_raise_unicorn_error(L):
     (5000, 136, 256, 1, False, True, True),       # N not a multiple of the tile (136 = 128 + 8), ReLU
 ])
 def test_gemm_h2_persistent(L, cfg, case):
-    """gemm_h2p.hip (cfg 144) against fp64 on the unrounded operands, next to the one-tile-per-block kernels."""
+    """gemm_h2p.hip (cfg 144) and gemm_h2q.hip (cfg 188: ping-pong wave groups, counted-vmcnt DMA stream across K steps and
+    tiles; K = 64 is its shortest stream, K = 160 an odd step count so the stage parity flips from tile to tile) against fp64 on
+    the unrounded operands, next to the one-tile-per-block kernels.  The schedule-sensitive kernel is also run three times and
+    must reproduce itself bit for bit (a DMA / fragment-read race shows up as run-to-run differences)."""
     M, N, K, act, use_res, use_F, use_B = case
     g = torch.Generator().manual_seed(M + N + K)
     x = (torch.randn(M, K, generator=g) * 2.0).cuda()
@@ -602,6 +605,14 @@ def test_gemm_h2_persistent(L, cfg, case):
     if use_B:
         dec, _, _ = h2_decode(outB, M, N)
         assert ((dec.double() - exp).abs() <= tol * 1.2 + exp.abs() * 2.0 ** -21).all()
+    if cfg == 188:
+        first = (outF.clone() if use_F else None, outB.clone() if use_B else None)
+        for _ in range(3):
+            L.check(L.lib().uni_gemm_h2(L.ptr(A), K, L.ptr(Wp), wscale, M, N, M, 1, K, 1, 1, 1, 0, L.ptr(bias), act, L.ptr(res), N,
+                                        L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
+            torch.cuda.synchronize()
+            assert first[0] is None or torch.equal(first[0], outF)
+            assert first[1] is None or torch.equal(first[1], outB)
 
 
 # ------------------------------------------------------------------------------------------------

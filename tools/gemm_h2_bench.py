@@ -53,7 +53,7 @@ for name, Hin, Win, Cin, N, k, act, use_res, use_F, use_B in SHAPES:
         def run():
             L.check(lib.uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), 1.0 / 128, M, N, Hin_, Win_, Cin, k, k, 1, pad, L.ptr(bias), act, L.ptr(res), N,
                                     L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
-        for _ in range(2):
+        for _ in range(2 if out else 12):          # the first column also warms the clocks up
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

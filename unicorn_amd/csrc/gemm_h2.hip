@@ -256,8 +256,14 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     }
     if (a.rowstat) UNI_REQUIRE(a.epi, "gemm(h2): rowstat needs the vector-aligned (staged) epilogue");
     if (!a.epi && (cfg == 44 || cfg == 48 || cfg == 42)) cfg = 22;
-    // plain GEMMs that take the 256 x 256 tile go to the persistent variant (gemm_h2p.hip); 144 forces it
-    if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_h2p_supported(a) && !getenv("UNI_NO_H2P")) cfg = 144;
+    // plain GEMMs that take the 256 x 256 tile go to the persistent variants: the ping-pong kernel (gemm_h2q.hip, 188), or
+    // gemm_h2p.hip (144) for what that one does not cover (LayerNorm fold, a single K step); UNI_NO_H2Q / UNI_NO_H2P = A/B switches
+    if (cfg == 44 && a.force_cfg % 1000 == 0 && !getenv("UNI_NO_H2P")) {
+        static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;
+        if (!no_q && gemm_h2q_supported(a)) cfg = 188;
+        else if (gemm_h2p_supported(a)) cfg = 144;
+    }
+    if (cfg == 188) return gemm_h2q_supported(a) ? launch_gemm_h2q(a, s) : (uni_set_error("gemm(h2): ping-pong variant does not support this problem"), -1);
     if (cfg == 144) return gemm_h2p_supported(a) ? launch_gemm_h2p(a, s) : (uni_set_error("gemm(h2): persistent variant does not support this problem"), -1);
 #define GOH(WM, WN, TM, TN) return conv ? launch_h2_cfg<WM, WN, TM, TN, true>(a, s) : launch_h2_cfg<WM, WN, TM, TN, false>(a, s)
     switch (cfg) {

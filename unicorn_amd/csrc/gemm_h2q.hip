@@ -1,0 +1,372 @@
+// PING-PONG variant of the persistent 256 x 256 split-f16 ("f16x2") GEMM (gemm_h2p.hip) for the plain contractions: ConvNeXt
+// pointwise MLPs and transformer Linears (convnext.py:41-54 pwconv1 / pwconv2; deformable_transformer.py:122-131).
+//
+// 8 waves = 2 wave groups (M halves) x 4 (N quarters), a wave owns 128 x 64 of the tile (128 accumulator registers).  A K step
+// (32 k = 128-byte LDS rows of [8 hi][8 lo] groups) is cut into four HALF-TILES of 128 rows -- A0, A1 (the first / second 64 rows
+// of both groups' M halves), B0, B1 (the first / second 32 columns of every wave's N quarter) -- and into four PHASES, one
+// 64 x 32 quadrant of the wave tile each:
+//      phase 1: reads A0 + B0, quadrant (A0, B0)        phase 3: reads A1, quadrant (A1, B1)
+//      phase 2: reads B1,      quadrant (A0, B1)        phase 4: (B0 kept), quadrant (A1, B0)
+// A phase is [ds_reads + one half-tile of LDS-DMA] | barrier | [12 MFMAs] | barrier, and the second wave group runs ONE BARRIER
+// BEHIND the first: while one group issues its MFMAs, the other one (same SIMDs) reads fragments and requests DMA, so the
+// matrix pipe never waits for LDS.  The DMA stream runs continuously over the K steps AND over the tiles of the persistent block,
+// ~2 steps ahead in two 64-KiB stages, drained by ONE counted `s_waitcnt vmcnt(6)` per K step (three half-tiles stay in flight
+// across every barrier, raw `s_barrier` only):
+//      half-tile:   B0(S+1)   A0(S+2)   B1(S+2)   A1(S+2)       requested in phase 1 / 2 / 3 / 4 of step S -- each ONE phase after
+//      last read:   p1(S-1)   p1(S)     p2(S)     p3(S)         the last read of the slot it overwrites (reads are retired with
+// lgkmcnt(0) before the barrier that ends their phase); after the wait in phase 4 every half-tile of step S+1 has landed for all
+// waves once both groups have passed their next barrier, i.e. before anybody's phase 1 of step S+1.
+// Epilogue = gemm_h2p.hip's (bias, activation, residual, fp32 / operand-format outputs through a per-wave 4-KiB
+// staging block), staged in its own 32 KiB so the DMA of the next tile keeps flying.
+#include "kernels.h"
+
+#define GLDS16R(gptr, lptr)                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+namespace {
+constexpr int NW = 8;
+constexpr int BM = 256, BN = 256, BKE = 32, ROWB = 128;
+constexpr int HALF = 128 * ROWB;                 // one half-tile: 128 rows x 128 B
+constexpr int STAGE = 4 * HALF;                  // A0 A1 B0 B1 of one K step
+constexpr int OPER = 2 * STAGE;
+constexpr int STG = 4096;                        // per-wave epilogue staging block
+constexpr int LDS_BYTES = OPER + NW * STG;       // 163840 = all of the CU's LDS
+
+struct Tile { int m0, n0; };
+__device__ __forceinline__ Tile tile_of(int L, int nbm, int nbn) {
+    constexpr int GN = 8;           // N is cut into chunks of 8 tiles; inside a chunk tiles run M-major (see gemm.hip)
+    const int per_chunk = nbm * GN;
+    const int c = L / per_chunk;
+    const int wc = min(GN, nbn - c * GN);
+    const int rem = L - c * per_chunk;
+    const int bm = rem / wc;
+    return {bm * BM, (c * GN + rem - bm * wc) * BN};
+}
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// raw workgroup barrier that neither the IR optimiser nor the machine scheduler moves anything across
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+}
+}  // namespace
+
+#define Q_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define Q_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int ACT, bool OUTF>
+__global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    int first, stride, count;
+    {
+        const int ntiles = nbm * nbn;
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = q + (x < r ? 1 : 0);
+        first = start + slot;
+        stride = nslots;
+        count = slot < cnt ? (cnt - slot + nslots - 1) / nslots : 0;
+    }
+    if (count == 0) return;
+
+    // ---- DMA: wave w fills pieces w and w + 8 (8 rows = 1 KiB each) of every half-tile; lane -> row lane / 8 of the piece, 16-byte
+    // chunk (lane & 7) of the LDS row, which holds the row's LOGICAL chunk lch (source-side swizzle with (LDS row >> 1) & 7).
+    // `buffer_load_dwordx4 ... lds` through one descriptor per operand and tile: base = first row of the tile, num_records = its
+    // valid rows (rows past M read as zeros, no clamp), per-lane offsets are the same for every tile and K step, the K step
+    // travels in the scalar offset.
+    const int lrow = lane >> 3;
+    const int lch = (lane & 7) ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
+    const int lda4 = p.lda * 4, ldw4 = p.Kpad * 4;
+    int voa[2][2], vob[2][2];                        // [half][piece]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            voa[h][i] = (8 * wave + lrow + 128 * i + 64 * h) * lda4 + lch * 16;                              // tile row arow + 128 i + 64 h
+            vob[h][i] = ((wave >> 2) * 64 + 8 * (wave & 3) + lrow + 128 * i + 32 * h) * ldw4 + lch * 16;     // tile column
+        }
+    auto rsrc_a = [&](Tile tl) __attribute__((always_inline)) {
+        const int rows = min(BM, p.M - tl.m0);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + (long)tl.m0 * lda4, 0, rows * lda4, 0x00020000);
+    };
+    auto rsrc_b = [&](Tile tl) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.W)) + (long)tl.n0 * ldw4, 0, BN * ldw4, 0x00020000);
+    };
+#define Q_DMA(rs, vo, soff, dst) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 16, vo, soff, 0, 0)
+    auto issueA = [&](int h, int par, int kt, __amdgpu_buffer_rsrc_t rs) __attribute__((always_inline)) {
+        char* dst = smem + par * STAGE + h * HALF + wave * 1024;
+        Q_DMA(rs, voa[h][0], kt * ROWB, dst);
+        Q_DMA(rs, voa[h][1], kt * ROWB, dst + 8192);
+    };
+    auto issueB = [&](int h, int par, int kt, __amdgpu_buffer_rsrc_t rs) __attribute__((always_inline)) {
+        char* dst = smem + par * STAGE + (2 + h) * HALF + wave * 1024;
+        Q_DMA(rs, vob[h][0], kt * ROWB, dst);
+        Q_DMA(rs, vob[h][1], kt * ROWB, dst + 8192);
+    };
+
+    // ---- fragment reads: group `grp` reads rows 64 grp + 32 i + fr of an A half, wave column wc rows 32 wc + fr of a B half;
+    // per lane four chunk addresses (hi / lo of k slice 0 / 1), everything else is an immediate offset
+    const int sw = (fr >> 1) & 7;
+    const int c0 = ((2 * fh) ^ sw) << 4, c1 = ((4 + 2 * fh) ^ sw) << 4;      // hi chunk of k slice 0 / 1; the lo chunk is ^ 16
+    const int a_rd = (grp * 64 + fr) * ROWB, b_rd = 2 * HALF + (wc * 32 + fr) * ROWB;
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int ra4[4] = {lds0 + a_rd + c0, lds0 + a_rd + (c0 ^ 16), lds0 + a_rd + c1, lds0 + a_rd + (c1 ^ 16)};
+    int rb4[4] = {lds0 + b_rd + c0, lds0 + b_rd + (c0 ^ 16), lds0 + b_rd + c1, lds0 + b_rd + (c1 ^ 16)};
+#define Q_LDS(addr, off) (*reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((size_t)((addr) + (off))))
+
+    f32x16 acc[4][2];
+    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];           // B fragments of both halves stay in registers (B0 serves phases 1 and 4)
+    const int nk = p.K / BKE;
+    Tile cur = tile_of(first, nbm, nbn);
+    Tile nxt = count > 1 ? tile_of(first + stride, nbm, nbn) : cur;
+    __amdgpu_buffer_rsrc_t ra_cur = rsrc_a(cur), rb_cur = rsrc_b(cur), ra_nxt = rsrc_a(nxt), rb_nxt = rsrc_b(nxt);
+
+#define Q_LD_A(h)                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                      \
+        ah[i][0] = Q_LDS(ra4[0], (h) * HALF + i * 32 * ROWB);            \
+        al[i][0] = Q_LDS(ra4[1], (h) * HALF + i * 32 * ROWB);            \
+        ah[i][1] = Q_LDS(ra4[2], (h) * HALF + i * 32 * ROWB);            \
+        al[i][1] = Q_LDS(ra4[3], (h) * HALF + i * 32 * ROWB);            \
+    }
+#define Q_LD_B(h)                                                       \
+    {                                                                   \
+        bh[h][0] = Q_LDS(rb4[0], (h) * HALF);                            \
+        bl[h][0] = Q_LDS(rb4[1], (h) * HALF);                            \
+        bh[h][1] = Q_LDS(rb4[2], (h) * HALF);                            \
+        bl[h][1] = Q_LDS(rb4[3], (h) * HALF);                            \
+    }
+    // quadrant (HA, HB): accumulator tiles (2 HA + i, HB); per k slice the two cross terms first, then hi.hi
+#define Q_MFMA(HA, HB)                                                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                                        \
+        acc[2 * (HA)][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[HB][kk], ah[0][kk], acc[2 * (HA)][HB], 0, 0, 0);            \
+        acc[2 * (HA) + 1][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[HB][kk], ah[1][kk], acc[2 * (HA) + 1][HB], 0, 0, 0);    \
+        acc[2 * (HA)][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], al[0][kk], acc[2 * (HA)][HB], 0, 0, 0);            \
+        acc[2 * (HA) + 1][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], al[1][kk], acc[2 * (HA) + 1][HB], 0, 0, 0);    \
+        acc[2 * (HA)][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], ah[0][kk], acc[2 * (HA)][HB], 0, 0, 0);            \
+        acc[2 * (HA) + 1][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], ah[1][kk], acc[2 * (HA) + 1][HB], 0, 0, 0);    \
+    }
+    // (k step, tile) `ahead` steps after the current one: the stream continues into the block's next tile
+#define Q_FUT(ahead)                                                   \
+    int fk = kt + (ahead);                                             \
+    const bool fnx = fk >= nk;                                         \
+    fk -= fnx ? nk : 0;                                                \
+    const __amdgpu_buffer_rsrc_t fa = fnx ? ra_nxt : ra_cur, fb = fnx ? rb_nxt : rb_cur;
+
+    // ---- prologue: step 0 completely, step 1 without its B0 (phase 1 of step 0 requests that one)
+    {
+        const int kt = 0;
+        issueA(0, 0, 0, ra_cur); issueB(0, 0, 0, rb_cur); issueB(1, 0, 0, rb_cur); issueA(1, 0, 0, ra_cur);
+        Q_FUT(1);
+        issueA(0, 1, fk, fa); issueB(1, 1, fk, fb); issueA(1, 1, fk, fa);
+    }
+    Q_WAIT_VM(6);
+    phase_barrier();
+    if (grp == 1) phase_barrier();                    // the second group runs one barrier behind
+    int par = 0;
+#pragma unroll 1
+    for (int t = 0; t < count; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            {   // phase 1
+                Q_LD_A(0); Q_LD_B(0);
+                if (!(p.dbg & 1)) { Q_FUT(1); issueB(0, par ^ 1, fk, fb); }
+                Q_WAIT_LDS();
+                phase_barrier();
+                if (!(p.dbg & 2)) { Q_MFMA(0, 0); }
+                phase_barrier();
+            }
+            {   // phase 2
+                Q_LD_B(1);
+                if (!(p.dbg & 1)) { Q_FUT(2); issueA(0, par, fk, fa); }
+                Q_WAIT_LDS();
+                phase_barrier();
+                if (!(p.dbg & 2)) { Q_MFMA(0, 1); }
+                phase_barrier();
+            }
+            {   // phase 3
+                Q_LD_A(1);
+                if (!(p.dbg & 1)) { Q_FUT(2); issueB(1, par, fk, fb); }
+                Q_WAIT_LDS();
+                phase_barrier();
+                if (!(p.dbg & 2)) { Q_MFMA(1, 1); }
+                phase_barrier();
+            }
+            {   // phase 4 (B0 is still in registers)
+                if (!(p.dbg & 1)) { Q_FUT(2); issueA(1, par, fk, fa); }
+                Q_WAIT_VM(6);
+                Q_WAIT_LDS();
+                phase_barrier();
+                if (!(p.dbg & 2)) { Q_MFMA(1, 0); }
+                phase_barrier();
+            }
+            par ^= 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ra4[q] ^= STAGE; rb4[q] ^= STAGE; }
+        }
+        // ---- tile done (the DMA stream is already inside the next tile)
+        const Tile done = cur;
+        cur = nxt; ra_cur = ra_nxt; rb_cur = rb_nxt;
+        if (t + 2 < count) { nxt = tile_of(first + (t + 2) * stride, nbm, nbn); ra_nxt = rsrc_a(nxt); rb_nxt = rsrc_b(nxt); }
+        char* st = smem + OPER + wave * STG;
+        const int nw0 = done.n0 + wc * 64;
+        const int rb0 = done.m0 + grp * 128;
+        if (p.dbg & 16) {                             // ablation: no drain, accumulators kept live
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+            if (sacc == 1.2345e-30f && p.outF) p.outF[0] = sacc;
+            continue;
+        }
+        const float ws = p.wscale;
+        // bias of the wave's 64 columns through SCALAR loads (constant address space): SMEM does not sit on the vector-memory
+        // counter, so no wait of the epilogue drains the DMA stream or the stores behind it.  Lane (fr, fh) owns columns 8 g + 4 fh + e.
+        float bv[2][16];
+        {
+            typedef float f32x8 __attribute__((ext_vector_type(8)));
+            const __attribute__((address_space(4))) float* bias = (const __attribute__((address_space(4))) float*)(p.bias);
+            if (nw0 + 64 <= p.N) {                              // uniform
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x8 b8 = *reinterpret_cast<const __attribute__((address_space(4))) f32x8*>(bias + nw0 + j * 32 + 8 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[j][4 * g + e] = fh ? b8[4 + e] : b8[e];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // 32 SGPRs at a time
+                }
+            } else {                                            // ragged last N tile: clamped element loads
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = nw0 + j * 32 + 8 * g + e;
+                            const float lo = bias[min(c, p.N - 1)], hi = bias[min(c + 4, p.N - 1)];
+                            bv[j][4 * g + e] = fh ? hi : lo;
+                        }
+            }
+        }
+        const bool has_res = OUTF && p.res != nullptr, has_b = p.outB != nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // residual rows of this 32 x 32 block requested first: their latency hides under the activation + staging below
+                f32x4 rv[4];
+                if (has_res) {
+                    const int c = lane & 7, rr = lane >> 3;
+                    const int col = nw0 + j * 32 + 4 * c;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int row = rb0 + i * 32 + tt * 8 + rr;
+                        const bool ok = row < p.M && col < p.N;
+                        rv[tt] = *reinterpret_cast<const f32x4*>(p.res + (ok ? (size_t)row * p.ldr + col : 0));
+                    }
+                }
+                // fp32 [32 rows][32 cols] of block (i, j): 128-B rows, float4 chunks XOR-swizzled with row & 7
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(acc[i][j][4 * g + e], ws, bv[j][4 * g + e]));
+                    *reinterpret_cast<f32x4*>(st + fr * 128 + (((2 * g + fh) ^ (fr & 7)) << 4)) = v;
+                }
+                wave_fence();
+                if (OUTF) {        // fp32 (+ residual) output, optional operand-format copy: 4 channels per lane, 8 rows per instruction
+                    const int c = lane & 7, rr = lane >> 3;
+                    const int col = nw0 + j * 32 + 4 * c;
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int r = tt * 8 + rr, row = rb0 + i * 32 + r;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 128 + ((c ^ (r & 7)) << 4));
+                        if (has_res) v += rv[tt];
+                        if (row < p.M && col < p.N) {
+                            *reinterpret_cast<f32x4*>(p.outF + (size_t)row * p.ldf + col) = v;
+                            if (has_b) act_store4(p.outB, (size_t)row * p.ldb + col, v[0], v[1], v[2], v[3], FMT_H2);
+                        }
+                    }
+                } else {           // operand-format output only: 8 channels (one 32-byte [hi | lo] group) per lane, 16 rows per instruction
+                    const int c = lane & 3, rr = lane >> 2;
+                    const int col = nw0 + j * 32 + 8 * c;
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int r = tt * 16 + rr, row = rb0 + i * 32 + r;
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 128 + (((2 * c) ^ (r & 7)) << 4));
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 128 + (((2 * c + 1) ^ (r & 7)) << 4));
+                        if (row < p.M && col < p.N) {
+                            const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            act_store8(p.outB, (size_t)row * p.ldb + col, v8, FMT_H2);
+                        }
+                    }
+                }
+                wave_fence();
+            }
+        }
+    }
+    Q_WAIT_VM(0);                                     // the stream's last requests (never consumed) must not outlive the block's LDS
+    if (grp == 0) phase_barrier();                    // barrier count of the two groups evens out
+}
+
+template <int ACT, bool OUTF>
+static int launch_h2q_inst(const GemmArgs& a, int grid, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+            uni_set_error("gemm_h2q: cannot reserve %d bytes of LDS", LDS_BYTES);
+            return -1;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_h2q_kernel<ACT, OUTF>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
+    return 0;
+}
+
+bool gemm_h2q_supported(const GemmArgs& a) { return gemm_h2p_supported(a) && a.K >= 2 * BKE && !a.rowstat; }   // the LayerNorm-fold option stays on gemm_h2p
+
+int launch_gemm_h2q(const GemmArgs& a, hipStream_t s) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ncu -= ncu % 8;
+    }
+    const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const int grid = ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu;
+    const bool f = a.outF != nullptr;
+    switch (a.act) {
+        case ACT_GELU: return f ? launch_h2q_inst<ACT_GELU, true>(a, grid, s) : launch_h2q_inst<ACT_GELU, false>(a, grid, s);
+        case ACT_RELU: return f ? launch_h2q_inst<ACT_RELU, true>(a, grid, s) : launch_h2q_inst<ACT_RELU, false>(a, grid, s);
+        default: return f ? launch_h2q_inst<ACT_NONE, true>(a, grid, s) : launch_h2q_inst<ACT_NONE, false>(a, grid, s);
+    }
+}

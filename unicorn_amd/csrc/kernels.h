@@ -38,6 +38,8 @@ int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persi
 bool gemm_p44_supported(const GemmArgs& a);
 int launch_gemm_h2p(const GemmArgs& a, hipStream_t s);    // gemm_h2p.hip: the same for the split-f16 format
 bool gemm_h2p_supported(const GemmArgs& a);
+int launch_gemm_h2q(const GemmArgs& a, hipStream_t s);    // gemm_h2q.hip: persistent 256x256, two wave groups ping-pong MFMA / LDS phases, counted-vmcnt DMA stream
+bool gemm_h2q_supported(const GemmArgs& a);
 
 // ---------------------------------------------------------------- norm.hip
 // Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.
