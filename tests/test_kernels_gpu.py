@@ -539,6 +539,54 @@ def test_gemm_h2(L, cfg, case):
         assert torch.allclose(s_got, s_ref, rtol=2e-5, atol=2e-2), (s_got - s_ref).abs().max()    # sums of ~1e5 |terms| that nearly cancel
 
 
+@pytest.mark.parametrize("case", [
+    # (Hin, Win, Cin, N, k, stride, pad, act, bias, G, fp32_out): several 256 x 256 tiles per persistent block
+    (200, 320, 64, 512, 3, 1, 1, 0, False, 16, True),      # head / FPN 3x3 + GroupNorm sums, 2 K steps per tap
+    (101, 163, 96, 384, 3, 2, 1, 0, True, 16, True),       # 3x3 stride 2, odd map (ragged M, padding on every side), cpg 24
+    (120, 160, 64, 256, 2, 2, 0, 0, True, 0, True),        # 2x2 / s2 downsample, no statistics
+    (160, 200, 128, 256, 1, 1, 0, 0, False, 16, True),     # 1x1 lateral conv + GroupNorm sums (plain DMA path, block-wide reduction)
+    (96, 96, 64, 256, 3, 1, 1, 1, True, 0, False),         # 3x3 + ReLU, operand-format output only (upsample_layer)
+])
+def test_gemm_h2q_conv_and_stats(L, case):
+    """gemm_h2q.hip as an implicit GEMM (buffer-descriptor gather: the tap travels in the scalar offset, out-of-image lanes
+    read zeros through the range check) and with the GroupNorm-statistics epilogue, against fp64 on the unrounded operands;
+    three launches must agree bit for bit (the fp64 statistics atomics excepted)."""
+    Hin, Win, Cin, N, k, stride, pad, act, use_bias, G, use_F = case
+    g = torch.Generator().manual_seed(Hin * 7 + N)
+    x = (torch.randn(1, Cin, Hin, Win, generator=g) * 2.0).cuda()
+    w = (torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    bias = (torch.randn(N, generator=g) * 0.1).cuda() if use_bias else None
+    ref = F.conv2d(x.double(), w.double().cuda(), bias.double() if use_bias else None, stride=stride, padding=pad)
+    mag = F.conv2d(x.abs().double(), w.abs().double().cuda(), None, stride=stride, padding=pad)
+    Hout, Wout = ref.shape[2:]
+    M = Hout * Wout
+    raw = ref.permute(0, 2, 3, 1).reshape(M, N)
+    mag = mag.permute(0, 2, 3, 1).reshape(M, N)
+    exp = ACTS[act](raw)
+    A = cast_h2(L, x.permute(0, 2, 3, 1).reshape(Hin * Win, Cin).contiguous())
+    Wp, wscale = pack_weight_h2(L, w)
+    tol = mag * 2.0 ** -20 + 1e-6
+    outs = []
+    for rep in range(3):
+        outF = torch.full((M, N), float("nan"), device="cuda") if use_F else None
+        outB = torch.zeros((M, N), device="cuda", dtype=torch.int32) if not use_F else None
+        stats = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
+        L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), wscale, M, N, Hin, Win, Cin, k, k, stride, pad, L.ptr(bias), act, None, N,
+                                    L.ptr(outF), N, L.ptr(outB), N, L.ptr(stats), (N // G) if G else 0, 188, L.stream_ptr()), "gemm_h2")
+        torch.cuda.synchronize()
+        got = outF.double() if use_F else h2_decode(outB, M, N)[0].double()
+        assert torch.isfinite(got).all()
+        assert ((got - exp).abs() <= tol * 1.2 + (0 if use_F else exp.abs() * 2.0 ** -21)).all(), ((got - exp).abs() / tol).max()
+        outs.append(outF if use_F else outB)
+        if G:
+            grp = raw.reshape(M, G, N // G)
+            s_ref = torch.stack([grp.sum((0, 2)), (grp ** 2).sum((0, 2))], 1)
+            s_got = stats[:2 * G].reshape(G, 2)
+            # fp32 partial sums per tile over ~1e6 O(1) terms that nearly cancel in the first column
+            assert torch.allclose(s_got, s_ref, rtol=2e-5, atol=0.5), (s_got - s_ref).abs().max()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_gemm_h2_large_and_subnormal_lo(L):
     """256x256-tile path on a pwconv-sized problem + operands whose lo halves are f16 SUBNORMALS (|x| ~ 1e-2): the MFMA
     must not flush them (error would jump from ~2^-22 to ~2^-12 relative)."""

@@ -126,6 +126,116 @@ __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&ac
     }
 }
 
+// ---- GroupNorm statistics of (acc + bias), PER SAMPLE (GemmArgs::stats): block-wide (uses __syncthreads), `red_lds` = (WM * BN * 2 + 128)
+// floats of LDS nobody else touches meanwhile.  acc must already carry the weight scale.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_stats(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int tid,
+                                           float* red_lds) {
+    constexpr int BN = 32 * TN * WN, BMt = 32 * TM * WM;
+    const int fr = lane & 31, fh = lane >> 5;
+    {
+        // GroupNorm statistics of (acc + bias), PER SAMPLE: a block tile may straddle samples of a batch, so the
+        // reduction runs once per sample present in the tile (one iteration except at sample boundaries).
+        // Pixel lanes are reduced with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps register index
+        // r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
+        float* red = red_lds;                                 // [WM][BN][2]
+        float* gacc = red + WM * BN * 2;                      // [64][2]
+        const int b_lo = m0 / p.Mper;
+        const int b_hi = min(p.M - 1, m0 + BMt - 1) / p.Mper;
+        for (int sb = b_lo; sb <= b_hi; ++sb) {
+            const int r_lo = sb * p.Mper, r_hi = min(r_lo + p.Mper, p.M);
+            __syncthreads();
+            if (tid < 128) gacc[tid] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float gs[1][16], gq[1][16];                    // one 32-column slab at a time (register budget of the 128-accumulator tiles)
+                {
+                    const int cbase = n0 + wn * 32 * TN + j * 32 + 4 * fh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = cbase + 8 * (r >> 2) + (r & 3);
+                        const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+                        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const int row = m0 + wm * 32 * TM + i * 32 + fr;
+                            const float v = acc[i][j][r] + bias;
+                            const bool in = row >= r_lo && row < r_hi;
+                            s_ += in ? v : 0.f;
+                            q_ += in ? v * v : 0.f;
+                        }
+                        gs[0][r] = s_;
+                        gq[0][r] = q_;
+                    }
+                }
+                float s8[8], q8[8];
+                {
+                    const bool up = (lane >> 4) & 1;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float ss = up ? gs[0][r] : gs[0][r + 8], sq = up ? gq[0][r] : gq[0][r + 8];
+                        float ks = up ? gs[0][r + 8] : gs[0][r], kq = up ? gq[0][r + 8] : gq[0][r];
+                        s8[r] = ks + __shfl_xor(ss, 16, 64);
+                        q8[r] = kq + __shfl_xor(sq, 16, 64);
+                    }
+                }
+                float s4[4], q4[4];
+                {
+                    const bool up = (lane >> 3) & 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
+                        float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
+                        s4[r] = ks + __shfl_xor(ss, 8, 64);
+                        q4[r] = kq + __shfl_xor(sq, 8, 64);
+                    }
+                }
+                float s2[2], q2[2];
+                {
+                    const bool up = (lane >> 2) & 1;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
+                        float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
+                        s2[r] = ks + __shfl_xor(ss, 4, 64);
+                        q2[r] = kq + __shfl_xor(sq, 4, 64);
+                    }
+                }
+                float s1, q1;
+                {
+                    const bool up = (lane >> 1) & 1;
+                    float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
+                    float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
+                    s1 = ks + __shfl_xor(ss, 2, 64);
+                    q1 = kq + __shfl_xor(sq, 2, 64);
+                }
+                s1 += __shfl_xor(s1, 1, 64);
+                q1 += __shfl_xor(q1, 1, 64);
+                if ((lane & 1) == 0) {
+                    const int r = (lane >> 1) & 15;
+                    const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                    red[(wm * BN + c) * 2 + 0] = s1;
+                    red[(wm * BN + c) * 2 + 1] = q1;
+                }
+            }
+            __syncthreads();
+            const int g_first = n0 / p.cpg;
+            if (tid < BN && n0 + tid < p.N) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < WM; ++w_) { s += red[(w_ * BN + tid) * 2]; q += red[(w_ * BN + tid) * 2 + 1]; }
+                int gl = (n0 + tid) / p.cpg - g_first;
+                atomicAdd(&gacc[gl * 2], s);
+                atomicAdd(&gacc[gl * 2 + 1], q);
+            }
+            __syncthreads();
+            const int nloc = (min(n0 + BN, p.N) - 1) / p.cpg - g_first + 1;
+            if (tid < nloc * 2)
+                atomicAdd(&p.stats[(size_t)sb * 64 + (g_first + (tid >> 1)) * 2 + (tid & 1)], (double)gacc[tid]);
+        }
+        }
+}
+
 // ---- shared epilogue: lane owns pixel row = m0 + wm*32*TM + i*32 + (lane&31) and, per accumulator quad g,
 // channels n0 + wn*32*TN + j*32 + 8g + 4*(lane>>5) + {0,1,2,3} ----
 template <int WM, int WN, int TM, int TN, bool STATS>
@@ -229,107 +339,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             }
         }
     }
-    if (STATS) {
-        // GroupNorm statistics of (acc + bias), PER SAMPLE: a block tile may straddle samples of a batch, so the
-        // reduction runs once per sample present in the tile (one iteration except at sample boundaries).
-        // Pixel lanes are reduced with a reduce-scatter butterfly: after offsets 16,8,4,2 lane l keeps register index
-        // r = (l>>1)&15 (bit4->r3, bit3->r2, bit2->r1, bit1->r0); offset 1 adds the twin lane.
-        float* red = reinterpret_cast<float*>(smem);          // [WM][BN][2]
-        float* gacc = red + WM * BN * 2;                      // [64][2]
-        const int b_lo = m0 / p.Mper;
-        const int b_hi = min(p.M - 1, m0 + BMt - 1) / p.Mper;
-        for (int sb = b_lo; sb <= b_hi; ++sb) {
-            const int r_lo = sb * p.Mper, r_hi = min(r_lo + p.Mper, p.M);
-            float gs[TN][16], gq[TN][16];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int cbase = n0 + wn * 32 * TN + j * 32 + 4 * fh;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = cbase + 8 * (r >> 2) + (r & 3);
-                    const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-                    float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int row = m0 + wm * 32 * TM + i * 32 + fr;
-                        const float v = acc[i][j][r] + bias;
-                        const bool in = row >= r_lo && row < r_hi;
-                        s_ += in ? v : 0.f;
-                        q_ += in ? v * v : 0.f;
-                    }
-                    gs[j][r] = s_;
-                    gq[j][r] = q_;
-                }
-            }
-            __syncthreads();
-            if (tid < 128) gacc[tid] = 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float s8[8], q8[8];
-                {
-                    const bool up = (lane >> 4) & 1;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float ss = up ? gs[j][r] : gs[j][r + 8], sq = up ? gq[j][r] : gq[j][r + 8];
-                        float ks = up ? gs[j][r + 8] : gs[j][r], kq = up ? gq[j][r + 8] : gq[j][r];
-                        s8[r] = ks + __shfl_xor(ss, 16, 64);
-                        q8[r] = kq + __shfl_xor(sq, 16, 64);
-                    }
-                }
-                float s4[4], q4[4];
-                {
-                    const bool up = (lane >> 3) & 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float ss = up ? s8[r] : s8[r + 4], sq = up ? q8[r] : q8[r + 4];
-                        float ks = up ? s8[r + 4] : s8[r], kq = up ? q8[r + 4] : q8[r];
-                        s4[r] = ks + __shfl_xor(ss, 8, 64);
-                        q4[r] = kq + __shfl_xor(sq, 8, 64);
-                    }
-                }
-                float s2[2], q2[2];
-                {
-                    const bool up = (lane >> 2) & 1;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        float ss = up ? s4[r] : s4[r + 2], sq = up ? q4[r] : q4[r + 2];
-                        float ks = up ? s4[r + 2] : s4[r], kq = up ? q4[r + 2] : q4[r];
-                        s2[r] = ks + __shfl_xor(ss, 4, 64);
-                        q2[r] = kq + __shfl_xor(sq, 4, 64);
-                    }
-                }
-                float s1, q1;
-                {
-                    const bool up = (lane >> 1) & 1;
-                    float ss = up ? s2[0] : s2[1], sq = up ? q2[0] : q2[1];
-                    float ks = up ? s2[1] : s2[0], kq = up ? q2[1] : q2[0];
-                    s1 = ks + __shfl_xor(ss, 2, 64);
-                    q1 = kq + __shfl_xor(sq, 2, 64);
-                }
-                s1 += __shfl_xor(s1, 1, 64);
-                q1 += __shfl_xor(q1, 1, 64);
-                if ((lane & 1) == 0) {
-                    const int r = (lane >> 1) & 15;
-                    const int c = wn * 32 * TN + j * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
-                    red[(wm * BN + c) * 2 + 0] = s1;
-                    red[(wm * BN + c) * 2 + 1] = q1;
-                }
-            }
-            __syncthreads();
-            const int g_first = n0 / p.cpg;
-            if (tid < BN && n0 + tid < p.N) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int w_ = 0; w_ < WM; ++w_) { s += red[(w_ * BN + tid) * 2]; q += red[(w_ * BN + tid) * 2 + 1]; }
-                int gl = (n0 + tid) / p.cpg - g_first;
-                atomicAdd(&gacc[gl * 2], s);
-                atomicAdd(&gacc[gl * 2 + 1], q);
-            }
-            __syncthreads();
-            const int nloc = (min(n0 + BN, p.N) - 1) / p.cpg - g_first + 1;
-            if (tid < nloc * 2)
-                atomicAdd(&p.stats[(size_t)sb * 64 + (g_first + (tid >> 1)) * 2 + (tid & 1)], (double)gacc[tid]);
-        }
-    }
+    if (STATS) gemm_stats<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem));
 }
 

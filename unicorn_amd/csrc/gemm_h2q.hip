@@ -19,6 +19,7 @@
 // Epilogue = gemm_h2p.hip's (bias, activation, residual, fp32 / operand-format outputs through a per-wave 4-KiB
 // staging block), staged in its own 32 KiB so the DMA of the next tile keeps flying.
 #include "kernels.h"
+#include "gemm_epi.h"
 
 #define GLDS16R(gptr, lptr)                                                                            \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
@@ -34,6 +35,9 @@ constexpr int STG = 4096;                        // per-wave epilogue staging bl
 constexpr int LDS_BYTES = OPER + NW * STG;       // 163840 = all of the CU's LDS
 
 struct Tile { int m0, n0; };
+// A side of a tile: buffer descriptor + per-lane offsets [half][piece]; CONV: byte offset (< 2^26, launcher checks) | validity bits << 26.
+// (At namespace scope: a struct local to the kernel template makes hipcc drop the host stubs of its instantiations.)
+struct ATile { __amdgpu_buffer_rsrc_t rs; int vo[2][2]; };
 __device__ __forceinline__ Tile tile_of(int L, int nbm, int nbn) {
     constexpr int GN = 8;           // N is cut into chunks of 8 tiles; inside a chunk tiles run M-major (see gemm.hip)
     const int per_chunk = nbm * GN;
@@ -61,7 +65,7 @@ __device__ __forceinline__ void phase_barrier() {
 #define Q_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define Q_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int ACT, bool OUTF>
+template <int ACT, bool OUTF, bool CONV, bool STATS>
 __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -92,27 +96,73 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     const int lrow = lane >> 3;
     const int lch = (lane & 7) ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
     const int lda4 = p.lda * 4, ldw4 = p.Kpad * 4;
-    int voa[2][2], vob[2][2];                        // [half][piece]
+    int vob[2][2];                                   // [half][piece]
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            voa[h][i] = (8 * wave + lrow + 128 * i + 64 * h) * lda4 + lch * 16;                              // tile row arow + 128 i + 64 h
-            vob[h][i] = ((wave >> 2) * 64 + 8 * (wave & 3) + lrow + 128 * i + 32 * h) * ldw4 + lch * 16;     // tile column
+        for (int i = 0; i < 2; ++i) vob[h][i] = ((wave >> 2) * 64 + 8 * (wave & 3) + lrow + 128 * i + 32 * h) * ldw4 + lch * 16;     // tile column
+    const int arow = 8 * wave + lrow;                // tile row of piece i, half h: arow + 128 i + 64 h
+    // A side of one tile.  Plain GEMM: the descriptor starts at the tile's first row, per-lane offsets are tile independent.
+    // Implicit GEMM (CONV; Cin % 32 == 0, so a K step = 32 channels of ONE tap): the descriptor starts (pad, pad) pixels before the
+    // tile's first input pixel, the per-lane offset is the lane's pixel relative to that, the tap (ky, kx) and the channel block
+    // travel in the scalar offset ((ky Win + kx) lda + c) -- never negative -- and a lane whose tap falls outside the image (or
+    // whose row is past M) presents an offset beyond num_records: the buffer load returns zeros, which IS the zero padding.
+    auto make_a = [&](Tile tl, ATile& c) __attribute__((always_inline)) {
+        char* abase = const_cast<char*>(reinterpret_cast<const char*>(p.A));
+        if (!CONV) {
+            const int rows = min(BM, p.M - tl.m0);
+            c.rs = __builtin_amdgcn_make_buffer_rsrc(abase + (long)tl.m0 * lda4, 0, rows * lda4, 0x00020000);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) c.vo[h][i] = (arow + 128 * i + 64 * h) * lda4 + lch * 16;
+        } else {
+            const int b0 = tl.m0 / p.Mper, q0 = tl.m0 - b0 * p.Mper, oy0 = q0 / p.Wout, ox0 = q0 - oy0 * p.Wout;
+            const int pix0 = (b0 * p.Hin + oy0 * p.stride) * p.Win + ox0 * p.stride;
+            c.rs = __builtin_amdgcn_make_buffer_rsrc(abase + ((long)pix0 - (p.pad * p.Win + p.pad)) * lda4, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = tl.m0 + arow + 128 * i + 64 * h;
+                    const bool ok = m < p.M;
+                    const int mm = ok ? m : tl.m0;
+                    const int b = mm / p.Mper, q = mm - b * p.Mper, oy = q / p.Wout, ox = q - oy * p.Wout;
+                    const int off = ((b * p.Hin + oy * p.stride) * p.Win + ox * p.stride - pix0) * lda4 + lch * 16;
+                    int bits = 0;                    // bit ky: input row of tap row ky inside the image; bit 3 + kx: the same for the column
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int iy = oy * p.stride - p.pad + t, ix = ox * p.stride - p.pad + t;
+                        bits |= (t < p.KH && iy >= 0 && iy < p.Hin) ? (1 << t) : 0;
+                        bits |= (t < p.KW && ix >= 0 && ix < p.Win) ? (8 << t) : 0;
+                    }
+                    c.vo[h][i] = off | ((ok ? bits : 0) << 26);
+                }
         }
-    auto rsrc_a = [&](Tile tl) __attribute__((always_inline)) {
-        const int rows = min(BM, p.M - tl.m0);
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + (long)tl.m0 * lda4, 0, rows * lda4, 0x00020000);
     };
     auto rsrc_b = [&](Tile tl) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.W)) + (long)tl.n0 * ldw4, 0, BN * ldw4, 0x00020000);
     };
+    const int cs = CONV ? p.Cin / BKE : 1;           // K steps per tap
+    const int csm = 65536 / cs + 1;                  // fk / cs = (fk * csm) >> 16 for fk < 9 cs <= 2^12 (launcher checks)
+    const int kwm = p.KW == 3 ? 11 : p.KW == 2 ? 16 : 32;   // tap / KW = (tap * kwm) >> 5 for tap < 9
 #define Q_DMA(rs, vo, soff, dst) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst), 16, vo, soff, 0, 0)
-    auto issueA = [&](int h, int par, int kt, __amdgpu_buffer_rsrc_t rs) __attribute__((always_inline)) {
+    auto issueA = [&](int h, int par, int kt, const ATile& c) __attribute__((always_inline)) {
         char* dst = smem + par * STAGE + h * HALF + wave * 1024;
-        Q_DMA(rs, voa[h][0], kt * ROWB, dst);
-        Q_DMA(rs, voa[h][1], kt * ROWB, dst + 8192);
+        if (!CONV) {
+            Q_DMA(c.rs, c.vo[h][0], kt * ROWB, dst);
+            Q_DMA(c.rs, c.vo[h][1], kt * ROWB, dst + 8192);
+        } else {
+            const int tap = (kt * csm) >> 16, cstep = kt - tap * cs;
+            const int ky = (tap * kwm) >> 5, kx = tap - ky * p.KW;
+            const int soff = (ky * p.Win + kx) * lda4 + cstep * ROWB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = ((c.vo[h][i] >> (26 + ky)) & (c.vo[h][i] >> (29 + kx)) & 1) != 0;
+                Q_DMA(c.rs, ok ? (c.vo[h][i] & 0x03ffffff) : 0x7fffffff, soff, dst + i * 8192);
+            }
+        }
     };
     auto issueB = [&](int h, int par, int kt, __amdgpu_buffer_rsrc_t rs) __attribute__((always_inline)) {
         char* dst = smem + par * STAGE + (2 + h) * HALF + wave * 1024;
@@ -135,7 +185,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     const int nk = p.K / BKE;
     Tile cur = tile_of(first, nbm, nbn);
     Tile nxt = count > 1 ? tile_of(first + stride, nbm, nbn) : cur;
-    __amdgpu_buffer_rsrc_t ra_cur = rsrc_a(cur), rb_cur = rsrc_b(cur), ra_nxt = rsrc_a(nxt), rb_nxt = rsrc_b(nxt);
+    ATile ta_cur, ta_nxt;
+    make_a(cur, ta_cur);
+    make_a(nxt, ta_nxt);
+    __amdgpu_buffer_rsrc_t rb_cur = rsrc_b(cur), rb_nxt = rsrc_b(nxt);
 
 #define Q_LD_A(h)                                                       \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                      \
@@ -166,12 +219,17 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     int fk = kt + (ahead);                                             \
     const bool fnx = fk >= nk;                                         \
     fk -= fnx ? nk : 0;                                                \
-    const __amdgpu_buffer_rsrc_t fa = fnx ? ra_nxt : ra_cur, fb = fnx ? rb_nxt : rb_cur;
+    const __amdgpu_buffer_rsrc_t fb = fnx ? rb_nxt : rb_cur;                                  \
+    ATile fa;                                                                                  \
+    fa.rs = fnx ? ta_nxt.rs : ta_cur.rs;                                                       \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {  \
+        fa.vo[h_][i_] = (CONV && fnx) ? ta_nxt.vo[h_][i_] : ta_cur.vo[h_][i_];                 \
+    }
 
     // ---- prologue: step 0 completely, step 1 without its B0 (phase 1 of step 0 requests that one)
     {
         const int kt = 0;
-        issueA(0, 0, 0, ra_cur); issueB(0, 0, 0, rb_cur); issueB(1, 0, 0, rb_cur); issueA(1, 0, 0, ra_cur);
+        issueA(0, 0, 0, ta_cur); issueB(0, 0, 0, rb_cur); issueB(1, 0, 0, rb_cur); issueA(1, 0, 0, ta_cur);
         Q_FUT(1);
         issueA(0, 1, fk, fa); issueB(1, 1, fk, fb); issueA(1, 1, fk, fa);
     }
@@ -227,8 +285,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
         }
         // ---- tile done (the DMA stream is already inside the next tile)
         const Tile done = cur;
-        cur = nxt; ra_cur = ra_nxt; rb_cur = rb_nxt;
-        if (t + 2 < count) { nxt = tile_of(first + (t + 2) * stride, nbm, nbn); ra_nxt = rsrc_a(nxt); rb_nxt = rsrc_b(nxt); }
+        cur = nxt; ta_cur = ta_nxt; rb_cur = rb_nxt;
+        if (t + 2 < count) { nxt = tile_of(first + (t + 2) * stride, nbm, nbn); make_a(nxt, ta_nxt); rb_nxt = rsrc_b(nxt); }
         char* st = smem + OPER + wave * STG;
         const int nw0 = done.n0 + wc * 64;
         const int rb0 = done.m0 + grp * 128;
@@ -243,42 +301,50 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
             if (sacc == 1.2345e-30f && p.outF) p.outF[0] = sacc;
             continue;
         }
-        const float ws = p.wscale;
+        if (STATS) {
+            // GroupNorm-statistics problems end with a block-wide reduction: the first wave group waits one barrier for the
+            // second one (which runs one barrier behind), both drain in step, and the second group re-staggers afterwards
+            if (grp == 0) phase_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.wscale;
+        }
+        const float ws = STATS ? 1.f : p.wscale;
         // bias of the wave's 64 columns through SCALAR loads (constant address space): SMEM does not sit on the vector-memory
         // counter, so no wait of the epilogue drains the DMA stream or the stores behind it.  Lane (fr, fh) owns columns 8 g + 4 fh + e.
-        float bv[2][16];
-        {
-            typedef float f32x8 __attribute__((ext_vector_type(8)));
-            const __attribute__((address_space(4))) float* bias = (const __attribute__((address_space(4))) float*)(p.bias);
-            if (nw0 + 64 <= p.N) {                              // uniform
+        const bool has_res = OUTF && !STATS && !CONV && p.res != nullptr, has_b = p.outB != nullptr;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j) {                  // 32-column slab of the wave tile: its bias once, then the four 32-row blocks
+            float bv[16];
+            {
+                typedef float f32x8 __attribute__((ext_vector_type(8)));
+                const __attribute__((address_space(4))) float* bias = (const __attribute__((address_space(4))) float*)(p.bias);
+                if (!p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+                } else if (nw0 + 64 <= p.N) {                   // uniform
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x8 b8 = *reinterpret_cast<const __attribute__((address_space(4))) f32x8*>(bias + nw0 + j * 32 + 8 * g);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) bv[j][4 * g + e] = fh ? b8[4 + e] : b8[e];
+                        for (int e = 0; e < 4; ++e) bv[4 * g + e] = fh ? b8[4 + e] : b8[e];
                     }
-                    __builtin_amdgcn_sched_barrier(0);          // 32 SGPRs at a time
-                }
-            } else {                                            // ragged last N tile: clamped element loads
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                } else {                                        // ragged last N tile: clamped element loads
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int c = nw0 + j * 32 + 8 * g + e;
                             const float lo = bias[min(c, p.N - 1)], hi = bias[min(c + 4, p.N - 1)];
-                            bv[j][4 * g + e] = fh ? hi : lo;
+                            bv[4 * g + e] = fh ? hi : lo;
                         }
+                }
             }
-        }
-        const bool has_res = OUTF && p.res != nullptr, has_b = p.outB != nullptr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < 4; ++i) {
                 // residual rows of this 32 x 32 block requested first: their latency hides under the activation + staging below
                 f32x4 rv[4];
                 if (has_res) {
@@ -296,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(acc[i][j][4 * g + e], ws, bv[j][4 * g + e]));
+                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(acc[i][j][4 * g + e], ws, bv[4 * g + e]));
                     *reinterpret_cast<f32x4*>(st + fr * 128 + (((2 * g + fh) ^ (fr & 7)) << 4)) = v;
                 }
                 wave_fence();
@@ -308,8 +374,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
                         const int r = tt * 8 + rr, row = rb0 + i * 32 + r;
                         f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 128 + ((c ^ (r & 7)) << 4));
                         if (has_res) v += rv[tt];
-                        if (row < p.M && col < p.N) {
-                            *reinterpret_cast<f32x4*>(p.outF + (size_t)row * p.ldf + col) = v;
+                        if (row < p.M && col < p.N && !(p.dbg & 4)) {
+                            const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
+                            *reinterpret_cast<f32x4*>(p.outF + (size_t)orow * p.ldf + col) = v;
                             if (has_b) act_store4(p.outB, (size_t)row * p.ldb + col, v[0], v[1], v[2], v[3], FMT_H2);
                         }
                     }
@@ -321,36 +388,63 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
                         const int r = tt * 16 + rr, row = rb0 + i * 32 + r;
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 128 + (((2 * c) ^ (r & 7)) << 4));
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 128 + (((2 * c + 1) ^ (r & 7)) << 4));
-                        if (row < p.M && col < p.N) {
+                        if (row < p.M && col < p.N && !(p.dbg & 4)) {
                             const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            act_store8(p.outB, (size_t)row * p.ldb + col, v8, FMT_H2);
+                            // streaming (non-temporal) stores: the consumer is the next launch and the tensor (786 MB for a stage-2
+                            // pwconv1) is far larger than L2, keeping it there only evicts the operand panels of this GEMM
+                            f16x8 h, l;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { f16 hh, ll; h2_split(v8[q], hh, ll); h[q] = hh; l[q] = ll; }
+                            char* op = reinterpret_cast<char*>(p.outB) + ((size_t)row * p.ldb + col) * 4;
+                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, h), reinterpret_cast<f32x4*>(op));
+                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, l), reinterpret_cast<f32x4*>(op + 16));
                         }
                     }
                 }
                 wave_fence();
             }
         }
+        if (STATS) {
+            gemm_stats<2, 4, 4, 2>(p, acc, done.m0, done.n0, grp, wc, lane, tid, reinterpret_cast<float*>(smem + OPER));
+            __syncthreads();                          // the reduction scratch is the waves' staging blocks
+            if (grp == 1) phase_barrier();
+        }
     }
     Q_WAIT_VM(0);                                     // the stream's last requests (never consumed) must not outlive the block's LDS
     if (grp == 0) phase_barrier();                    // barrier count of the two groups evens out
 }
 
-template <int ACT, bool OUTF>
+template <int ACT, bool OUTF, bool CONV, bool STATS>
 static int launch_h2q_inst(const GemmArgs& a, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF, CONV, STATS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
             uni_set_error("gemm_h2q: cannot reserve %d bytes of LDS", LDS_BYTES);
             return -1;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_h2q_kernel<ACT, OUTF>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_h2q_kernel<ACT, OUTF, CONV, STATS>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
     return 0;
 }
 
-bool gemm_h2q_supported(const GemmArgs& a) { return gemm_h2p_supported(a) && a.K >= 2 * BKE && !a.rowstat; }   // the LayerNorm-fold option stays on gemm_h2p
+// plain GEMMs: what gemm_h2p takes minus the LayerNorm fold; implicit GEMMs (3x3 / strided convs) and GroupNorm-statistics
+// problems: 32-channel-aligned taps, fp32 output, no activation window
+bool gemm_h2q_supported(const GemmArgs& a) {
+    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    if (a.b32 != FMT_H2 || !a.epi || a.K % BKE != 0 || a.K < 2 * BKE || a.rowstat || a.act_col0 != 0) return false;
+    if (!conv && !a.stats) return gemm_h2p_supported(a);
+    if (conv) {
+        if (a.Cin % BKE != 0 || a.KH > 3 || a.KW > 3 || a.K != a.KH * a.KW * a.Cin || a.Cin / BKE > 448) return false;
+        // the input pixels of one 256-row tile must lie within 2^26 bytes of its first one (the per-lane offsets carry 6 flag bits)
+        const long span_pix = ((long)BM / a.Wout + 2) * a.stride * a.Win + (long)BM * a.stride + 3L * a.Win;
+        if (span_pix * a.lda * 4 >= (1L << 26)) return false;
+    }
+    if (a.res) return false;                         // residual adds only on the plain path
+    if (a.stats) return a.act == ACT_NONE && a.outF != nullptr && a.cpg > 0 && 256 / a.cpg + 2 <= 64;
+    return a.outF != nullptr ? (a.act == ACT_NONE || a.act == ACT_RELU) : (a.outB != nullptr && !a.res && !a.out_hw && (a.act == ACT_NONE || a.act == ACT_RELU));
+}
 
 int launch_gemm_h2q(const GemmArgs& a, hipStream_t s) {
     static int ncu = 0;
@@ -364,9 +458,15 @@ int launch_gemm_h2q(const GemmArgs& a, hipStream_t s) {
     const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int grid = ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu;
     const bool f = a.outF != nullptr;
+    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    if (a.stats) return conv ? launch_h2q_inst<ACT_NONE, true, true, true>(a, grid, s) : launch_h2q_inst<ACT_NONE, true, false, true>(a, grid, s);
+    if (conv) {
+        if (a.act == ACT_RELU) return f ? launch_h2q_inst<ACT_RELU, true, true, false>(a, grid, s) : launch_h2q_inst<ACT_RELU, false, true, false>(a, grid, s);
+        return f ? launch_h2q_inst<ACT_NONE, true, true, false>(a, grid, s) : launch_h2q_inst<ACT_NONE, false, true, false>(a, grid, s);
+    }
     switch (a.act) {
-        case ACT_GELU: return f ? launch_h2q_inst<ACT_GELU, true>(a, grid, s) : launch_h2q_inst<ACT_GELU, false>(a, grid, s);
-        case ACT_RELU: return f ? launch_h2q_inst<ACT_RELU, true>(a, grid, s) : launch_h2q_inst<ACT_RELU, false>(a, grid, s);
-        default: return f ? launch_h2q_inst<ACT_NONE, true>(a, grid, s) : launch_h2q_inst<ACT_NONE, false>(a, grid, s);
+        case ACT_GELU: return f ? launch_h2q_inst<ACT_GELU, true, false, false>(a, grid, s) : launch_h2q_inst<ACT_GELU, false, false, false>(a, grid, s);
+        case ACT_RELU: return f ? launch_h2q_inst<ACT_RELU, true, false, false>(a, grid, s) : launch_h2q_inst<ACT_RELU, false, false, false>(a, grid, s);
+        default: return f ? launch_h2q_inst<ACT_NONE, true, false, false>(a, grid, s) : launch_h2q_inst<ACT_NONE, false, false, false>(a, grid, s);
     }
 }
