@@ -170,7 +170,8 @@ def test_layernorm(L, C_):
 
 
 @pytest.mark.parametrize("shape", [(96, 20, 24), (192, 13, 10), (256, 25, 40), (384, 9, 16), (768, 10, 10), (1536, 5, 8),
-                                   (192, 101, 163), (192, 151, 163), (768, 49, 83)])   # last three: 8-px and 2-row variants
+                                   (192, 101, 163), (192, 151, 163), (768, 49, 83),     # 8-px and 2-row variants
+                                   (768, 127, 163), (256, 207, 323), (192, 261, 317), (384, 255, 163)])   # persistent LDS-weight variant (in-wave / LDS reduction)
 def test_dwconv7_ln(L, shape):
     C_, H, W = shape
     g = torch.Generator().manual_seed(C_ + H)

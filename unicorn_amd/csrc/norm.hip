@@ -406,6 +406,196 @@ __global__ __launch_bounds__(384) void dwconv7_ln2_kernel(DwLnArgs p, int S, int
     }
 }
 
+// The same 2-row x 8-px x 4-channel thread as a PERSISTENT block for C = 64 k channels (a wave = 64 channel groups of ONE strip, so
+// everything about the strip is wave-uniform):
+//   * input rows through a BUFFER DESCRIPTOR per row (base = row start, num_records = row bytes or 0 for a row outside the
+//     image) and 14 per-lane offsets computed once per strip: a pixel left / right of the row is an offset outside the
+//     descriptor and reads zeros -- no bounds branches (the kernel above spends ~45 branches per row on them), no 64-bit
+//     address math, and few enough registers for
+//   * a register double buffer: the next input row is in flight while this one is multiplied (the kernel above exposes the L2
+//     round trip of every row: 2 waves per SIMD cannot cover it);
+//   * the 49 x C weights resident in LDS (conflict-free 16-byte reads) instead of 6 weight float4s per output float4 through the
+//     vector L1, which a 150 KB table (C = 768) does not fit;
+//   * LayerNorm sums reduced inside the waves (reduce-scatter butterfly: 17 shuffles for the 16 pixels), 64 B of scratch per wave.
+template <int C>                                               // compile-time: the tap offsets become instruction immediates
+__global__ __launch_bounds__(512) void dwconv7_ln2b_kernel(DwLnArgs p, int S, int spr, int nstrips) {
+    constexpr int PX = 8, IN = PX + 6, CG = C / 4;
+    extern __shared__ float lds[];
+    float* wl = lds;                                             // [49][C]
+    float* red = lds + 49 * C;                                   // [waves][16]
+    const int tid = threadIdx.x;
+    for (int u = tid; u < 49 * C / 4; u += blockDim.x) reinterpret_cast<f32x4*>(wl)[u] = reinterpret_cast<const f32x4*>(p.w)[u];
+    __syncthreads();
+    constexpr int wps = (CG + 63) >> 6;                          // waves per strip; C = 192 / 384 leave the lanes past CG idle
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = wv / wps, cg0 = (wv - sl * wps) * 64 + lane;
+    const bool lane_ok = cg0 < CG;
+    const int cg = lane_ok ? cg0 : 0;                            // idle lanes shadow channel group 0 and store nothing
+    int first, step, count;
+    {
+        const int nblk = (nstrips + S - 1) / S;
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = q + (x < r ? 1 : 0);
+        first = start + slot;
+        step = nslots;
+        count = slot < cnt ? (cnt - slot + nslots - 1) / nslots : 0;
+    }
+    const int HP = (p.H + 1) >> 1;                               // row pairs per image
+    constexpr float invC = 1.f / (float)C;
+    const int rowbytes = p.W * C * 4;
+    // sum over the lanes of a wave of 16 values at once: afterwards every lane holds the total of value
+    // ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
+    auto wave_scatter_sum = [&](const float (&v)[16]) __attribute__((always_inline)) {
+        float a8[8], a4[4], a2[2], a1;
+        {
+            const bool up = (lane >> 5) & 1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a8[r] = (up ? v[r + 8] : v[r]) + __shfl_xor(up ? v[r] : v[r + 8], 32, 64);
+        }
+        {
+            const bool up = (lane >> 4) & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a4[r] = (up ? a8[r + 4] : a8[r]) + __shfl_xor(up ? a8[r] : a8[r + 4], 16, 64);
+        }
+        {
+            const bool up = (lane >> 3) & 1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) a2[r] = (up ? a4[r + 2] : a4[r]) + __shfl_xor(up ? a4[r] : a4[r + 2], 8, 64);
+        }
+        {
+            const bool up = (lane >> 2) & 1;
+            a1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 4, 64);
+        }
+        a1 += __shfl_xor(a1, 2, 64);
+        return a1 + __shfl_xor(a1, 1, 64);
+    };
+    auto reduce16 = [&](const float (&part)[16], float (&tot)[16]) __attribute__((always_inline)) {
+        const float t = wave_scatter_sum(part);
+        if ((lane & 3) == 0) red[wv * 16 + (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1))] = t;
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float t2 = 0.f;
+            for (int w_ = 0; w_ < wps; ++w_) t2 += red[(sl * wps + w_) * 16 + o];     // fixed order: deterministic
+            tot[o] = t2;
+        }
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int it = 0; it < count; ++it) {
+        asm volatile("" ::: "memory");                           // keep the 49 weight reads inside the row loop (hoisted out of this loop they cost 196 registers)
+        const int strip = (first + it * step) * S + sl;          // wave-uniform
+        const bool active = sl < S && strip < nstrips;
+        const int yg = active ? strip / spr : 0;
+        const int x0 = active ? (strip - yg * spr) * PX : 0;
+        const int sb = yg / HP, y = (yg - sb * HP) * 2;          // sample, first of the two output rows
+        const size_t img0 = (size_t)sb * p.H * p.W;
+        f32x4 acc0[PX], acc1[PX];
+        {
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
+#pragma unroll
+            for (int o = 0; o < PX; ++o) { acc0[o] = bias4; acc1[o] = bias4; }
+        }
+        if (active) {
+            // one per-lane offset (the channel group) for all loads; the pixel travels in the scalar offset and a pixel outside the
+            // row (wave-uniform) or a row outside the image gets num_records = 0: the load returns zeros
+            auto load_row = [&](f32x4 (&dst)[IN], int iy) __attribute__((always_inline)) {
+                const bool rok = iy >= 0 && iy < p.H;
+                float* rowp = const_cast<float*>(p.x) + (img0 + (size_t)(rok ? iy : 0) * p.W) * C;
+#pragma unroll
+                for (int j = 0; j < IN; ++j) {
+                    const int ix = x0 + j - 3;
+                    const bool ok = rok && ix >= 0 && ix < p.W;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, ok ? rowbytes : 0, 0x00020000);
+                    dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cg * 16, ok ? ix * C * 4 : 0, 0));
+                }
+            };
+            auto mac_row = [&](const f32x4 (&src)[IN], int r) __attribute__((always_inline)) {   // input row y-3+r: ky = r for row y, r-1 for row y+1
+                if (r < 7) {
+                    const float* wrow = wl + (r * 7) * C + cg * 4;
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * C);
+#pragma unroll
+                        for (int o = 0; o < PX; ++o)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc0[o][e] = fmaf(w[e], src[o + kx][e], acc0[o][e]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);               // one 7-tap weight row (28 registers) at a time
+                if (r > 0) {
+                    const float* wrow = wl + ((r - 1) * 7) * C + cg * 4;
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * C);
+#pragma unroll
+                        for (int o = 0; o < PX; ++o)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc1[o][e] = fmaf(w[e], src[o + kx][e], acc1[o][e]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#ifdef UNI_DW_PREFETCH
+            f32x4 ra[IN], rb[IN];
+            load_row(ra, y - 3);
+#pragma unroll 1
+            for (int rp = 0; rp < 4; ++rp) {
+                load_row(rb, y - 2 + 2 * rp);
+                mac_row(ra, 2 * rp);
+                if (rp < 3) load_row(ra, y - 1 + 2 * rp);
+                mac_row(rb, 2 * rp + 1);
+            }
+#else
+            f32x4 ra[IN];
+#pragma unroll 1
+            for (int r = 0; r < 8; ++r) {
+                load_row(ra, y - 3 + r);
+                mac_row(ra, r);
+            }
+#endif
+        }
+        float part[2 * PX], tot[2 * PX], mean[2 * PX];
+#pragma unroll
+        for (int o = 0; o < PX; ++o) {
+            part[o] = lane_ok ? acc0[o][0] + acc0[o][1] + acc0[o][2] + acc0[o][3] : 0.f;
+            part[PX + o] = lane_ok ? acc1[o][0] + acc1[o][1] + acc1[o][2] + acc1[o][3] : 0.f;
+        }
+        reduce16(part, tot);
+#pragma unroll
+        for (int o = 0; o < PX; ++o) {
+            mean[o] = tot[o] * invC;
+            mean[PX + o] = tot[PX + o] * invC;
+            float a = acc0[o][0] - mean[o], b = acc0[o][1] - mean[o], c = acc0[o][2] - mean[o], d = acc0[o][3] - mean[o];
+            part[o] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
+            a = acc1[o][0] - mean[PX + o]; b = acc1[o][1] - mean[PX + o]; c = acc1[o][2] - mean[PX + o]; d = acc1[o][3] - mean[PX + o];
+            part[PX + o] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
+        }
+        reduce16(part, tot);
+        if (active && lane_ok) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + cg * 4);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cg * 4);
+#pragma unroll
+            for (int o = 0; o < PX; ++o) {
+                if (x0 + o < p.W) {
+                    float rstd = rsqrtf(tot[o] * invC + p.eps);
+                    act_store4(p.out, (img0 + (size_t)y * p.W + x0 + o) * C + cg * 4, (acc0[o][0] - mean[o]) * rstd * g[0] + be[0],
+                               (acc0[o][1] - mean[o]) * rstd * g[1] + be[1], (acc0[o][2] - mean[o]) * rstd * g[2] + be[2],
+                               (acc0[o][3] - mean[o]) * rstd * g[3] + be[3], p.b32);
+                    if (y + 1 < p.H) {
+                        rstd = rsqrtf(tot[PX + o] * invC + p.eps);
+                        act_store4(p.out, (img0 + (size_t)(y + 1) * p.W + x0 + o) * C + cg * 4,
+                                   (acc1[o][0] - mean[PX + o]) * rstd * g[0] + be[0], (acc1[o][1] - mean[PX + o]) * rstd * g[1] + be[1],
+                                   (acc1[o][2] - mean[PX + o]) * rstd * g[2] + be[2], (acc1[o][3] - mean[PX + o]) * rstd * g[3] + be[3], p.b32);
+                    }
+                }
+            }
+        }
+    }
+}
+
 int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     UNI_REQUIRE(a.C % 4 == 0 && a.C / 4 <= 512, "dwconv7_ln: C=%d unsupported", a.C);
     const int CG = a.C / 4;
@@ -421,6 +611,33 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     if (env) px = atoi(env);
     if (px == 16) {
         const int spr = cdiv(a.W, 8), nstrips = spr * ((a.H + 1) / 2) * nb;
+        // persistent variant (row descriptors, register double buffer, weights in LDS): C a multiple of 256, 49 C floats + scratch
+        // within 160 KB, at least two rounds of work for 256 CUs and a row shorter than 2 GiB / 4
+        static const bool no_b = getenv("UNI_DW_NOLDSW") != nullptr;
+        if (!no_b && (long)a.W * a.C * 4 < (1L << 30) && (a.C == 192 || a.C == 256 || a.C == 384 || a.C == 512 || a.C == 768)) {
+            const int wps = cdiv(CG, 64), Sw = 8 / wps;          // 512 threads: 8 waves
+            const size_t ldsw = (size_t)49 * a.C * 4 + (size_t)8 * 16 * 4;
+            if (cdiv(nstrips, Sw) >= 512) {
+                static bool attr_done = false;
+                if (!attr_done) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    attr_done = true;
+                }
+                const dim3 grid(256), block(Sw * wps * 64);
+                switch (a.C) {
+                    case 192: hipLaunchKernelGGL(dwconv7_ln2b_kernel<192>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
+                    case 256: hipLaunchKernelGGL(dwconv7_ln2b_kernel<256>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
+                    case 384: hipLaunchKernelGGL(dwconv7_ln2b_kernel<384>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
+                    case 512: hipLaunchKernelGGL(dwconv7_ln2b_kernel<512>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
+                    default: hipLaunchKernelGGL(dwconv7_ln2b_kernel<768>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
+                }
+                return 0;
+            }
+        }
         hipLaunchKernelGGL(dwconv7_ln2_kernel, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 16), s, a, S, CG, spr, nstrips);
         return 0;
     }
