@@ -417,8 +417,10 @@ __global__ __launch_bounds__(384) void dwconv7_ln2_kernel(DwLnArgs p, int S, int
 //   * the 49 x C weights resident in LDS (conflict-free 16-byte reads) instead of 6 weight float4s per output float4 through the
 //     vector L1, which a 150 KB table (C = 768) does not fit;
 //   * LayerNorm sums reduced inside the waves (reduce-scatter butterfly: 17 shuffles for the 16 pixels), 64 B of scratch per wave.
-template <int C>                                               // compile-time: the tap offsets become instruction immediates
-__global__ __launch_bounds__(512) void dwconv7_ln2b_kernel(DwLnArgs p, int S, int spr, int nstrips) {
+// ROWS = 4 output rows per thread: the measured bound of these kernels is the L2 -> CU load path (~22-25 B/clk/CU, the same figure
+// the GEMM's LDS-DMA sees), and 10 input rows for 4 output rows is 4.4 input float4s per output float4 instead of 7.
+template <int C, int ROWS>                                     // C compile-time: the tap offsets become instruction immediates
+__global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int spr, int nstrips) {
     constexpr int PX = 8, IN = PX + 6, CG = C / 4;
     extern __shared__ float lds[];
     float* wl = lds;                                             // [49][C]
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln2b_kernel(DwLnArgs p, int S, in
         step = nslots;
         count = slot < cnt ? (cnt - slot + nslots - 1) / nslots : 0;
     }
-    const int HP = (p.H + 1) >> 1;                               // row pairs per image
+    const int HP = (p.H + ROWS - 1) / ROWS;                      // row groups per image
     constexpr float invC = 1.f / (float)C;
     const int rowbytes = p.W * C * 4;
     // sum over the lanes of a wave of 16 values at once: afterwards every lane holds the total of value
@@ -490,13 +492,15 @@ __global__ __launch_bounds__(512) void dwconv7_ln2b_kernel(DwLnArgs p, int S, in
         const bool active = sl < S && strip < nstrips;
         const int yg = active ? strip / spr : 0;
         const int x0 = active ? (strip - yg * spr) * PX : 0;
-        const int sb = yg / HP, y = (yg - sb * HP) * 2;          // sample, first of the two output rows
+        const int sb = yg / HP, y = (yg - sb * HP) * ROWS;       // sample, first of the output rows
         const size_t img0 = (size_t)sb * p.H * p.W;
-        f32x4 acc0[PX], acc1[PX];
+        f32x4 acc[ROWS][PX];
         {
             const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
 #pragma unroll
-            for (int o = 0; o < PX; ++o) { acc0[o] = bias4; acc1[o] = bias4; }
+            for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+                for (int o = 0; o < PX; ++o) acc[q][o] = bias4;
         }
         if (active) {
             // one per-lane offset (the channel group) for all loads; the pixel travels in the scalar offset and a pixel outside the
@@ -512,83 +516,69 @@ __global__ __launch_bounds__(512) void dwconv7_ln2b_kernel(DwLnArgs p, int S, in
                     dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cg * 16, ok ? ix * C * 4 : 0, 0));
                 }
             };
-            auto mac_row = [&](const f32x4 (&src)[IN], int r) __attribute__((always_inline)) {   // input row y-3+r: ky = r for row y, r-1 for row y+1
-                if (r < 7) {
-                    const float* wrow = wl + (r * 7) * C + cg * 4;
+            auto mac_row = [&](const f32x4 (&src)[IN], int r) __attribute__((always_inline)) {   // input row y-3+r: tap row ky = r - q for output row y+q
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * C);
+                for (int q = 0; q < ROWS; ++q) {
+                    if (r - q >= 0 && r - q < 7) {               // wave-uniform
+                        const float* wrow = wl + ((r - q) * 7) * C + cg * 4;
 #pragma unroll
-                        for (int o = 0; o < PX; ++o)
+                        for (int kx = 0; kx < 7; ++kx) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * C);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc0[o][e] = fmaf(w[e], src[o + kx][e], acc0[o][e]);
+                            for (int o = 0; o < PX; ++o)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[q][o][e] = fmaf(w[e], src[o + kx][e], acc[q][o][e]);
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0);           // one 7-tap weight row (28 registers) at a time
                 }
-                __builtin_amdgcn_sched_barrier(0);               // one 7-tap weight row (28 registers) at a time
-                if (r > 0) {
-                    const float* wrow = wl + ((r - 1) * 7) * C + cg * 4;
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * C);
-#pragma unroll
-                        for (int o = 0; o < PX; ++o)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc1[o][e] = fmaf(w[e], src[o + kx][e], acc1[o][e]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
             };
-#ifdef UNI_DW_PREFETCH
-            f32x4 ra[IN], rb[IN];
-            load_row(ra, y - 3);
-#pragma unroll 1
-            for (int rp = 0; rp < 4; ++rp) {
-                load_row(rb, y - 2 + 2 * rp);
-                mac_row(ra, 2 * rp);
-                if (rp < 3) load_row(ra, y - 1 + 2 * rp);
-                mac_row(rb, 2 * rp + 1);
-            }
-#else
+            // (a register double buffer of the input row -- next row in flight while this one is multiplied -- needs 56 more
+            // registers and spills at the 256 this block size allows; PMC: the waves wait ~50 % of their time on those loads)
             f32x4 ra[IN];
 #pragma unroll 1
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < 6 + ROWS; ++r) {
                 load_row(ra, y - 3 + r);
                 mac_row(ra, r);
             }
-#endif
         }
-        float part[2 * PX], tot[2 * PX], mean[2 * PX];
+        // LayerNorm per pixel: two-pass (mean, then centred variance), 16 pixels per reduction
+        float mean[ROWS][PX], rstd[ROWS][PX];
 #pragma unroll
-        for (int o = 0; o < PX; ++o) {
-            part[o] = lane_ok ? acc0[o][0] + acc0[o][1] + acc0[o][2] + acc0[o][3] : 0.f;
-            part[PX + o] = lane_ok ? acc1[o][0] + acc1[o][1] + acc1[o][2] + acc1[o][3] : 0.f;
-        }
-        reduce16(part, tot);
+        for (int h = 0; h < ROWS / 2; ++h) {
+            float part[16], tot[16];
 #pragma unroll
-        for (int o = 0; o < PX; ++o) {
-            mean[o] = tot[o] * invC;
-            mean[PX + o] = tot[PX + o] * invC;
-            float a = acc0[o][0] - mean[o], b = acc0[o][1] - mean[o], c = acc0[o][2] - mean[o], d = acc0[o][3] - mean[o];
-            part[o] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
-            a = acc1[o][0] - mean[PX + o]; b = acc1[o][1] - mean[PX + o]; c = acc1[o][2] - mean[PX + o]; d = acc1[o][3] - mean[PX + o];
-            part[PX + o] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 v = acc[2 * h + (u >> 3)][u & 7];
+                part[u] = lane_ok ? v[0] + v[1] + v[2] + v[3] : 0.f;
+            }
+            reduce16(part, tot);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float m = tot[u] * invC;
+                mean[2 * h + (u >> 3)][u & 7] = m;
+                const f32x4 v = acc[2 * h + (u >> 3)][u & 7];
+                const float a = v[0] - m, b = v[1] - m, c = v[2] - m, d = v[3] - m;
+                part[u] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
+            }
+            reduce16(part, tot);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rstd[2 * h + (u >> 3)][u & 7] = rsqrtf(tot[u] * invC + p.eps);
         }
-        reduce16(part, tot);
         if (active && lane_ok) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + cg * 4);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cg * 4);
 #pragma unroll
-            for (int o = 0; o < PX; ++o) {
-                if (x0 + o < p.W) {
-                    float rstd = rsqrtf(tot[o] * invC + p.eps);
-                    act_store4(p.out, (img0 + (size_t)y * p.W + x0 + o) * C + cg * 4, (acc0[o][0] - mean[o]) * rstd * g[0] + be[0],
-                               (acc0[o][1] - mean[o]) * rstd * g[1] + be[1], (acc0[o][2] - mean[o]) * rstd * g[2] + be[2],
-                               (acc0[o][3] - mean[o]) * rstd * g[3] + be[3], p.b32);
-                    if (y + 1 < p.H) {
-                        rstd = rsqrtf(tot[PX + o] * invC + p.eps);
-                        act_store4(p.out, (img0 + (size_t)(y + 1) * p.W + x0 + o) * C + cg * 4,
-                                   (acc1[o][0] - mean[PX + o]) * rstd * g[0] + be[0], (acc1[o][1] - mean[PX + o]) * rstd * g[1] + be[1],
-                                   (acc1[o][2] - mean[PX + o]) * rstd * g[2] + be[2], (acc1[o][3] - mean[PX + o]) * rstd * g[3] + be[3], p.b32);
+            for (int q = 0; q < ROWS; ++q) {
+                if (y + q < p.H) {
+#pragma unroll
+                    for (int o = 0; o < PX; ++o) {
+                        if (x0 + o < p.W) {
+                            const float m = mean[q][o], rs = rstd[q][o];
+                            act_store4(p.out, (img0 + (size_t)(y + q) * p.W + x0 + o) * C + cg * 4, (acc[q][o][0] - m) * rs * g[0] + be[0],
+                                       (acc[q][o][1] - m) * rs * g[1] + be[1], (acc[q][o][2] - m) * rs * g[2] + be[2],
+                                       (acc[q][o][3] - m) * rs * g[3] + be[3], p.b32);
+                        }
                     }
                 }
             }
@@ -615,27 +605,27 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
         // within 160 KB, at least two rounds of work for 256 CUs and a row shorter than 2 GiB / 4
         static const bool no_b = getenv("UNI_DW_NOLDSW") != nullptr;
         if (!no_b && (long)a.W * a.C * 4 < (1L << 30) && (a.C == 192 || a.C == 256 || a.C == 384 || a.C == 512 || a.C == 768)) {
+            // output rows per thread: 4 (4.4 input float4s per output float4 instead of 7) except for C = 768, where its 16 spilled
+            // registers and the 50-row maps (13 groups of 4) cost more than the traffic saves (tools/dwln_bench.py)
+            static const int rows_env = getenv("UNI_DW_ROWS") ? atoi(getenv("UNI_DW_ROWS")) : 0;
+            const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (a.C == 768 ? 2 : 4);
             const int wps = cdiv(CG, 64), Sw = 8 / wps;          // 512 threads: 8 waves
             const size_t ldsw = (size_t)49 * a.C * 4 + (size_t)8 * 16 * 4;
-            if (cdiv(nstrips, Sw) >= 512) {
+            const int nst = spr * cdiv(a.H, rows) * nb;
+            if (cdiv(nst, Sw) >= 384) {
                 static bool attr_done = false;
+#define DWB_ALL(F) F(192, 2) F(256, 2) F(384, 2) F(512, 2) F(768, 2) F(192, 4) F(256, 4) F(384, 4) F(512, 4) F(768, 4)
                 if (!attr_done) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln2b_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+#define DWB_ATTR(CC, RR) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                    DWB_ALL(DWB_ATTR)
+#undef DWB_ATTR
                     attr_done = true;
                 }
                 const dim3 grid(256), block(Sw * wps * 64);
-                switch (a.C) {
-                    case 192: hipLaunchKernelGGL(dwconv7_ln2b_kernel<192>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
-                    case 256: hipLaunchKernelGGL(dwconv7_ln2b_kernel<256>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
-                    case 384: hipLaunchKernelGGL(dwconv7_ln2b_kernel<384>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
-                    case 512: hipLaunchKernelGGL(dwconv7_ln2b_kernel<512>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
-                    default: hipLaunchKernelGGL(dwconv7_ln2b_kernel<768>, grid, block, ldsw, s, a, Sw, spr, nstrips); break;
-                }
-                return 0;
+#define DWB_GO(CC, RR) if (a.C == CC && rows == RR) { hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, RR>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
+                DWB_ALL(DWB_GO)
+#undef DWB_GO
+#undef DWB_ALL
             }
         }
         hipLaunchKernelGGL(dwconv7_ln2_kernel, dim3(cdiv(nstrips, S)), dim3(T), strip_reduce_lds(S, CG, 16), s, a, S, CG, spr, nstrips);
