@@ -260,7 +260,7 @@ def main():
             traffic = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
         except Exception:
             tsrc = None
-        kname = {"bf16": "gemm_bf16_kernel / gemm_bf16_p44_kernel", "f16x2": "gemm_h2_kernel", "fp32": "gemm_f32_kernel"}[args.precision]
+        kname = {"bf16": "gemm_bf16_kernel / gemm_bf16_p44_kernel", "f16x2": "gemm_h2q_kernel / gemm_h2_kernel", "fp32": "gemm_f32_kernel"}[args.precision]
         roof = {"kernel": kname + " (all instantiations)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "peak_note": "dense 16-bit MFMA 2500 TFLOP/s / %d MFMAs per fp32-equivalent product" % mfma_per_product if mfma_per_product > 1 else "dense MFMA peak of the dtype",
