@@ -131,6 +131,70 @@ def test_gemm_large(L, cfg, case):
         assert (outB.float() - exp).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize("case", [
+    # plain: (M, N, K, act, res, outF, outB);  conv: (Hin, Win, Cin, N, k, stride, pad, act, bias, G, fp32_out)
+    ("plain", 70001, 256, 128, 2, False, False, True),     # two 64-k steps per tile (the shortest DMA stream), GELU, bf16 out, ragged M
+    ("plain", 35003, 512, 192, 0, True, True, True),       # odd step count (stage parity flips from tile to tile), residual + fp32 + bf16 out
+    ("plain", 9001, 3072, 320, 2, False, False, True),     # pwconv1-like
+    ("plain", 20000, 768, 1024, 0, True, True, False),     # pwconv2-like, fp32 out only
+    ("plain", 5000, 136, 256, 1, False, True, True),       # N not a multiple of the tile, ReLU
+    ("conv", 200, 320, 64, 512, 3, 1, 1, 0, False, 16, True),     # 3x3 + GroupNorm sums, one step per tap
+    ("conv", 101, 163, 128, 384, 3, 2, 1, 0, True, 16, True),     # 3x3 stride 2, odd map
+    ("conv", 120, 160, 64, 256, 2, 2, 0, 0, True, 0, True),       # 2x2 / s2 downsample
+    ("conv", 160, 200, 128, 256, 1, 1, 0, 0, False, 16, True),    # 1x1 + GroupNorm sums
+    ("conv", 96, 96, 64, 256, 3, 1, 1, 1, True, 0, False),        # 3x3 + ReLU, bf16 output only
+])
+def test_gemm_bf16_pingpong(L, case):
+    """The bf16 instantiations of the ping-pong persistent kernel (gemm_h2q.hip, cfg 188) against fp32 on the same bf16-rounded
+    operands; three launches must agree bit for bit (fp64 statistics atomics excepted)."""
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    if case[0] == "plain":
+        _, M, N, K, act, use_res, use_F, use_B = case
+        x = bf16_round(torch.randn(M, K, generator=g)).cuda()
+        w = bf16_round(torch.randn(N, K, generator=g) / K ** 0.5)
+        bias = (torch.randn(N, generator=g) * 0.1).cuda()
+        res = torch.randn(M, N, generator=g).cuda() if use_res else None
+        raw = x @ w.cuda().t() + bias
+        A = x.to(torch.bfloat16)
+        Wp = pack_weight(L, w.reshape(N, K, 1, 1))
+        geo = (M, 1, K, 1, 1, 1, 0)
+        G = 0
+    else:
+        _, Hin, Win, Cin, N, k, stride, pad, act, use_bias, G, use_F = case
+        use_B, use_res, res = not use_F, False, None
+        x = bf16_round(torch.randn(1, Cin, Hin, Win, generator=g)).cuda()
+        w = bf16_round(torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+        bias = (torch.randn(N, generator=g) * 0.1).cuda() if use_bias else None
+        ref = F.conv2d(x, w.cuda(), bias, stride=stride, padding=pad)
+        M = ref.shape[2] * ref.shape[3]
+        raw = ref.permute(0, 2, 3, 1).reshape(M, N)
+        A = x.permute(0, 2, 3, 1).reshape(Hin * Win, Cin).contiguous().to(torch.bfloat16)
+        Wp = pack_weight(L, w)
+        K = Cin
+        geo = (Hin, Win, Cin, k, k, stride, pad)
+    exp = ACTS[act](raw) + (res if use_res else 0)
+    scale = max(1.0, exp.abs().max().item())
+    outs = []
+    for rep in range(3):
+        outF = torch.full((M, N), float("nan"), device="cuda") if use_F else None
+        outB = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16) if use_B else None
+        stats = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
+        L.check(L.lib().uni_gemm_bf16(L.ptr(A), K, L.ptr(Wp), M, N, *geo, L.ptr(bias), act, L.ptr(res), N,
+                                      L.ptr(outF), N, L.ptr(outB), N, L.ptr(stats), (N // G) if G else 0, 188, L.stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        if use_F:
+            assert torch.isfinite(outF).all() and (outF - exp).abs().max().item() < 2e-3 * scale
+        if use_B:
+            assert torch.isfinite(outB.float()).all() and (outB.float() - exp).abs().max().item() < 1e-2 * scale
+        if G:
+            grp = raw.reshape(M, G, N // G).double()
+            s_ref = torch.stack([grp.sum((0, 2)), (grp ** 2).sum((0, 2))], 1)
+            assert torch.allclose(stats[:2 * G].reshape(G, 2), s_ref, rtol=1e-3, atol=1.0)
+        outs.append((outF, outB))
+    for o in outs[1:]:
+        assert (o[0] is None or torch.equal(o[0], outs[0][0])) and (o[1] is None or torch.equal(o[1], outs[0][1]))
+
+
 def test_gemm_act_col0(L):
     g = torch.Generator().manual_seed(5)
     M, K, N = 300, 256, 5

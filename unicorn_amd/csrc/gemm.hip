@@ -386,6 +386,16 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         else cfg = b21 >= 400 ? 21 : 11;
     }
 #define GO(WM, WN, TM, TN, BK) return conv ? launch_cfg<WM, WN, TM, TN, BK, true>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false>(a, s)
+    // 256-wide problems with whole rounds of tiles go to the persistent ping-pong kernel (gemm_h2q.hip, the bf16 instantiations;
+    // 188 forces it, UNI_NO_H2Q = A/B switch back to the kernels below)
+    {
+        static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;
+        const bool rounds = b44 >= 384 || (b44 >= 180 && b44 <= 256);
+        if (cfg == 188 || (a.force_cfg % 1000 == 0 && !no_q && a.N > 64 && util44 >= 0.74 && rounds && a.epi && gemm_h2q_supported(a))) {
+            if (!gemm_h2q_supported(a)) { uni_set_error("gemm: ping-pong variant does not support this problem"); return -1; }
+            return launch_gemm_h2q(a, s);
+        }
+    }
     // plain GEMMs that would take the 256x256 tile go to the persistent variant (gemm_p44.hip): -5..-20 % on the MLP shapes
     if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_p44_supported(a) && !no_p44) cfg = 144;
     if (cfg == 144 && !gemm_p44_supported(a)) cfg = 44;

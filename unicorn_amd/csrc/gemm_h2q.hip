@@ -65,8 +65,13 @@ __device__ __forceinline__ void phase_barrier() {
 #define Q_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define Q_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int ACT, bool OUTF, bool CONV, bool STATS>
+// FMT = FMT_H2: split-f16 operands, 32 k per step, 3 MFMAs per product; FMT = FMT_BF16: the bf16 twin on the same schedule -- 64 k per
+// step in the same 128-byte rows, 4 k slices, 1 MFMA per product (its 8-MFMA phases are shorter than the LDS/DMA phases: that
+// mode is bound by the L2 -> LDS path, not by the matrix pipe)
+template <int ACT, bool OUTF, bool CONV, bool STATS, int FMT>
 __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
+    constexpr int EB = FMT == FMT_H2 ? 4 : 2;          // bytes per operand element
+    constexpr int KS = ROWB / EB;                      // k per step: 32 (f16x2) or 64 (bf16)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     // travels in the scalar offset.
     const int lrow = lane >> 3;
     const int lch = (lane & 7) ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
-    const int lda4 = p.lda * 4, ldw4 = p.Kpad * 4;
+    const int lda4 = p.lda * EB, ldw4 = p.Kpad * EB;   // row strides in bytes
     int vob[2][2];                                   // [half][piece]
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     auto rsrc_b = [&](Tile tl) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.W)) + (long)tl.n0 * ldw4, 0, BN * ldw4, 0x00020000);
     };
-    const int cs = CONV ? p.Cin / BKE : 1;           // K steps per tap
+    const int cs = CONV ? p.Cin / KS : 1;            // K steps per tap
     const int csm = 65536 / cs + 1;                  // fk / cs = (fk * csm) >> 16 for fk < 9 cs <= 2^12 (launcher checks)
     const int kwm = p.KW == 3 ? 11 : p.KW == 2 ? 16 : 32;   // tap / KW = (tap * kwm) >> 5 for tap < 9
 #define Q_DMA(rs, vo, soff, dst) \
@@ -173,16 +178,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     // ---- fragment reads: group `grp` reads rows 64 grp + 32 i + fr of an A half, wave column wc rows 32 wc + fr of a B half;
     // per lane four chunk addresses (hi / lo of k slice 0 / 1), everything else is an immediate offset
     const int sw = (fr >> 1) & 7;
-    const int c0 = ((2 * fh) ^ sw) << 4, c1 = ((4 + 2 * fh) ^ sw) << 4;      // hi chunk of k slice 0 / 1; the lo chunk is ^ 16
+    // f16x2: chunks (hi, lo) of k slice 0, (hi, lo) of k slice 1 = 2 fh, 2 fh + 1, 4 + 2 fh, 5 + 2 fh;  bf16: k slices 0..3 = fh, 2 + fh, 4 + fh, 6 + fh
+    const int q0 = FMT == FMT_H2 ? 2 * fh : fh, q1 = FMT == FMT_H2 ? 2 * fh + 1 : 2 + fh;
+    const int q2 = FMT == FMT_H2 ? 4 + 2 * fh : 4 + fh, q3 = FMT == FMT_H2 ? 5 + 2 * fh : 6 + fh;
     const int a_rd = (grp * 64 + fr) * ROWB, b_rd = 2 * HALF + (wc * 32 + fr) * ROWB;
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
-    int ra4[4] = {lds0 + a_rd + c0, lds0 + a_rd + (c0 ^ 16), lds0 + a_rd + c1, lds0 + a_rd + (c1 ^ 16)};
-    int rb4[4] = {lds0 + b_rd + c0, lds0 + b_rd + (c0 ^ 16), lds0 + b_rd + c1, lds0 + b_rd + (c1 ^ 16)};
+    int ra4[4] = {lds0 + a_rd + ((q0 ^ sw) << 4), lds0 + a_rd + ((q1 ^ sw) << 4), lds0 + a_rd + ((q2 ^ sw) << 4), lds0 + a_rd + ((q3 ^ sw) << 4)};
+    int rb4[4] = {lds0 + b_rd + ((q0 ^ sw) << 4), lds0 + b_rd + ((q1 ^ sw) << 4), lds0 + b_rd + ((q2 ^ sw) << 4), lds0 + b_rd + ((q3 ^ sw) << 4)};
 #define Q_LDS(addr, off) (*reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((size_t)((addr) + (off))))
 
     f32x16 acc[4][2];
-    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];           // B fragments of both halves stay in registers (B0 serves phases 1 and 4)
-    const int nk = p.K / BKE;
+    // fragment registers [.][0..3]: f16x2 = (hi, lo) of k slice 0, (hi, lo) of k slice 1; bf16 = k slices 0..3.  B fragments of both
+    // halves stay in registers (B0 serves phases 1 and 4)
+    f16x8 fa[2][4], fb[2][4];
+    const int nk = p.K / KS;
     Tile cur = tile_of(first, nbm, nbn);
     Tile nxt = count > 1 ? tile_of(first + stride, nbm, nbn) : cur;
     ATile ta_cur, ta_nxt;
@@ -190,29 +199,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     make_a(nxt, ta_nxt);
     __amdgpu_buffer_rsrc_t rb_cur = rsrc_b(cur), rb_nxt = rsrc_b(nxt);
 
-#define Q_LD_A(h)                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                      \
-        ah[i][0] = Q_LDS(ra4[0], (h) * HALF + i * 32 * ROWB);            \
-        al[i][0] = Q_LDS(ra4[1], (h) * HALF + i * 32 * ROWB);            \
-        ah[i][1] = Q_LDS(ra4[2], (h) * HALF + i * 32 * ROWB);            \
-        al[i][1] = Q_LDS(ra4[3], (h) * HALF + i * 32 * ROWB);            \
-    }
-#define Q_LD_B(h)                                                       \
-    {                                                                   \
-        bh[h][0] = Q_LDS(rb4[0], (h) * HALF);                            \
-        bl[h][0] = Q_LDS(rb4[1], (h) * HALF);                            \
-        bh[h][1] = Q_LDS(rb4[2], (h) * HALF);                            \
-        bl[h][1] = Q_LDS(rb4[3], (h) * HALF);                            \
-    }
+#define Q_LD_A(h)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int q = 0; q < 4; ++q)      \
+        fa[i][q] = Q_LDS(ra4[q], (h) * HALF + i * 32 * ROWB);
+#define Q_LD_B(h) _Pragma("unroll") for (int q = 0; q < 4; ++q) fb[h][q] = Q_LDS(rb4[q], (h) * HALF);
     // quadrant (HA, HB): accumulator tiles (2 HA + i, HB); per k slice the two cross terms first, then hi.hi
-#define Q_MFMA(HA, HB)                                                                                                        \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                                        \
-        acc[2 * (HA)][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[HB][kk], ah[0][kk], acc[2 * (HA)][HB], 0, 0, 0);            \
-        acc[2 * (HA) + 1][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[HB][kk], ah[1][kk], acc[2 * (HA) + 1][HB], 0, 0, 0);    \
-        acc[2 * (HA)][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], al[0][kk], acc[2 * (HA)][HB], 0, 0, 0);            \
-        acc[2 * (HA) + 1][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], al[1][kk], acc[2 * (HA) + 1][HB], 0, 0, 0);    \
-        acc[2 * (HA)][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], ah[0][kk], acc[2 * (HA)][HB], 0, 0, 0);            \
-        acc[2 * (HA) + 1][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[HB][kk], ah[1][kk], acc[2 * (HA) + 1][HB], 0, 0, 0);    \
+#define Q_MF16(b, a, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c, 0, 0, 0)
+#define Q_MB16(b, a, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0)
+#define Q_MFMA(HA, HB)                                                                                   \
+    if (FMT == FMT_H2) {                                                                                 \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                               \
+            Q_MF16(fb[HB][2 * kk + 1], fa[0][2 * kk], acc[2 * (HA)][HB]);                                \
+            Q_MF16(fb[HB][2 * kk + 1], fa[1][2 * kk], acc[2 * (HA) + 1][HB]);                            \
+            Q_MF16(fb[HB][2 * kk], fa[0][2 * kk + 1], acc[2 * (HA)][HB]);                                \
+            Q_MF16(fb[HB][2 * kk], fa[1][2 * kk + 1], acc[2 * (HA) + 1][HB]);                            \
+            Q_MF16(fb[HB][2 * kk], fa[0][2 * kk], acc[2 * (HA)][HB]);                                    \
+            Q_MF16(fb[HB][2 * kk], fa[1][2 * kk], acc[2 * (HA) + 1][HB]);                                \
+        }                                                                                                \
+    } else {                                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                               \
+            Q_MB16(fb[HB][kk], fa[0][kk], acc[2 * (HA)][HB]);                                            \
+            Q_MB16(fb[HB][kk], fa[1][kk], acc[2 * (HA) + 1][HB]);                                        \
+        }                                                                                                \
     }
     // (k step, tile) `ahead` steps after the current one: the stream continues into the block's next tile
 #define Q_FUT(ahead)                                                   \
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
                         if (row < p.M && col < p.N && !(p.dbg & 4)) {
                             const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
                             *reinterpret_cast<f32x4*>(p.outF + (size_t)orow * p.ldf + col) = v;
-                            if (has_b) act_store4(p.outB, (size_t)row * p.ldb + col, v[0], v[1], v[2], v[3], FMT_H2);
+                            if (has_b) act_store4(p.outB, (size_t)row * p.ldb + col, v[0], v[1], v[2], v[3], FMT);
                         }
                     }
                 } else {           // operand-format output only: 8 channels (one 32-byte [hi | lo] group) per lane, 16 rows per instruction
@@ -392,12 +400,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
                             const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             // streaming (non-temporal) stores: the consumer is the next launch and the tensor (786 MB for a stage-2
                             // pwconv1) is far larger than L2, keeping it there only evicts the operand panels of this GEMM
-                            f16x8 h, l;
+                            if (FMT == FMT_H2) {
+                                f16x8 h, l;
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) { f16 hh, ll; h2_split(v8[q], hh, ll); h[q] = hh; l[q] = ll; }
-                            char* op = reinterpret_cast<char*>(p.outB) + ((size_t)row * p.ldb + col) * 4;
-                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, h), reinterpret_cast<f32x4*>(op));
-                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, l), reinterpret_cast<f32x4*>(op + 16));
+                                for (int q = 0; q < 8; ++q) { f16 hh, ll; h2_split(v8[q], hh, ll); h[q] = hh; l[q] = ll; }
+                                char* op = reinterpret_cast<char*>(p.outB) + ((size_t)row * p.ldb + col) * 4;
+                                __builtin_nontemporal_store(__builtin_bit_cast(f32x4, h), reinterpret_cast<f32x4*>(op));
+                                __builtin_nontemporal_store(__builtin_bit_cast(f32x4, l), reinterpret_cast<f32x4*>(op + 16));
+                            } else {
+                                bf16x8 o;
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) o[q] = (bf16)v8[q];
+                                __builtin_nontemporal_store(__builtin_bit_cast(f32x4, o), reinterpret_cast<f32x4*>(p.outB + (size_t)row * p.ldb + col));
+                            }
                         }
                     }
                 }
@@ -414,36 +429,54 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     if (grp == 0) phase_barrier();                    // barrier count of the two groups evens out
 }
 
-template <int ACT, bool OUTF, bool CONV, bool STATS>
+template <int ACT, bool OUTF, bool CONV, bool STATS, int FMT>
 static int launch_h2q_inst(const GemmArgs& a, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF, CONV, STATS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF, CONV, STATS, FMT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
             uni_set_error("gemm_h2q: cannot reserve %d bytes of LDS", LDS_BYTES);
             return -1;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_h2q_kernel<ACT, OUTF, CONV, STATS>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_h2q_kernel<ACT, OUTF, CONV, STATS, FMT>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
     return 0;
 }
 
-// plain GEMMs: what gemm_h2p takes minus the LayerNorm fold; implicit GEMMs (3x3 / strided convs) and GroupNorm-statistics
-// problems: 32-channel-aligned taps, fp32 output, no activation window
+// plain GEMMs: what the older persistent kernels take minus the LayerNorm fold; implicit GEMMs (3x3 / strided convs) and
+// GroupNorm-statistics problems: step-aligned taps (Cin a multiple of the 32 / 64 k of a step), fp32 output, no activation window
 bool gemm_h2q_supported(const GemmArgs& a) {
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
-    if (a.b32 != FMT_H2 || !a.epi || a.K % BKE != 0 || a.K < 2 * BKE || a.rowstat || a.act_col0 != 0) return false;
-    if (!conv && !a.stats) return gemm_h2p_supported(a);
+    if (a.b32 != FMT_H2 && a.b32 != FMT_BF16) return false;
+    const int ks = a.b32 == FMT_H2 ? 32 : 64, eb = a.b32 == FMT_H2 ? 4 : 2;
+    if (!a.epi || a.K % ks != 0 || a.K < 2 * ks || a.rowstat || a.act_col0 != 0) return false;
+    if (!conv && !a.stats) return a.b32 == FMT_H2 ? gemm_h2p_supported(a) : gemm_p44_supported(a);
     if (conv) {
-        if (a.Cin % BKE != 0 || a.KH > 3 || a.KW > 3 || a.K != a.KH * a.KW * a.Cin || a.Cin / BKE > 448) return false;
+        if (a.Cin % ks != 0 || a.KH > 3 || a.KW > 3 || a.K != a.KH * a.KW * a.Cin || a.Cin / ks > 448) return false;
         // the input pixels of one 256-row tile must lie within 2^26 bytes of its first one (the per-lane offsets carry 6 flag bits)
         const long span_pix = ((long)BM / a.Wout + 2) * a.stride * a.Win + (long)BM * a.stride + 3L * a.Win;
-        if (span_pix * a.lda * 4 >= (1L << 26)) return false;
+        if (span_pix * a.lda * eb >= (1L << 26)) return false;
     }
     if (a.res) return false;                         // residual adds only on the plain path
     if (a.stats) return a.act == ACT_NONE && a.outF != nullptr && a.cpg > 0 && 256 / a.cpg + 2 <= 64;
     return a.outF != nullptr ? (a.act == ACT_NONE || a.act == ACT_RELU) : (a.outB != nullptr && !a.res && !a.out_hw && (a.act == ACT_NONE || a.act == ACT_RELU));
+}
+
+template <int FMT>
+static int launch_h2q_fmt(const GemmArgs& a, int grid, hipStream_t s) {
+    const bool f = a.outF != nullptr;
+    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    if (a.stats) return conv ? launch_h2q_inst<ACT_NONE, true, true, true, FMT>(a, grid, s) : launch_h2q_inst<ACT_NONE, true, false, true, FMT>(a, grid, s);
+    if (conv) {
+        if (a.act == ACT_RELU) return f ? launch_h2q_inst<ACT_RELU, true, true, false, FMT>(a, grid, s) : launch_h2q_inst<ACT_RELU, false, true, false, FMT>(a, grid, s);
+        return f ? launch_h2q_inst<ACT_NONE, true, true, false, FMT>(a, grid, s) : launch_h2q_inst<ACT_NONE, false, true, false, FMT>(a, grid, s);
+    }
+    switch (a.act) {
+        case ACT_GELU: return f ? launch_h2q_inst<ACT_GELU, true, false, false, FMT>(a, grid, s) : launch_h2q_inst<ACT_GELU, false, false, false, FMT>(a, grid, s);
+        case ACT_RELU: return f ? launch_h2q_inst<ACT_RELU, true, false, false, FMT>(a, grid, s) : launch_h2q_inst<ACT_RELU, false, false, false, FMT>(a, grid, s);
+        default: return f ? launch_h2q_inst<ACT_NONE, true, false, false, FMT>(a, grid, s) : launch_h2q_inst<ACT_NONE, false, false, false, FMT>(a, grid, s);
+    }
 }
 
 int launch_gemm_h2q(const GemmArgs& a, hipStream_t s) {
@@ -457,16 +490,5 @@ int launch_gemm_h2q(const GemmArgs& a, hipStream_t s) {
     }
     const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int grid = ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu;
-    const bool f = a.outF != nullptr;
-    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
-    if (a.stats) return conv ? launch_h2q_inst<ACT_NONE, true, true, true>(a, grid, s) : launch_h2q_inst<ACT_NONE, true, false, true>(a, grid, s);
-    if (conv) {
-        if (a.act == ACT_RELU) return f ? launch_h2q_inst<ACT_RELU, true, true, false>(a, grid, s) : launch_h2q_inst<ACT_RELU, false, true, false>(a, grid, s);
-        return f ? launch_h2q_inst<ACT_NONE, true, true, false>(a, grid, s) : launch_h2q_inst<ACT_NONE, false, true, false>(a, grid, s);
-    }
-    switch (a.act) {
-        case ACT_GELU: return f ? launch_h2q_inst<ACT_GELU, true, false, false>(a, grid, s) : launch_h2q_inst<ACT_GELU, false, false, false>(a, grid, s);
-        case ACT_RELU: return f ? launch_h2q_inst<ACT_RELU, true, false, false>(a, grid, s) : launch_h2q_inst<ACT_RELU, false, false, false>(a, grid, s);
-        default: return f ? launch_h2q_inst<ACT_NONE, true, false, false>(a, grid, s) : launch_h2q_inst<ACT_NONE, false, false, false>(a, grid, s);
-    }
+    return a.b32 == FMT_H2 ? launch_h2q_fmt<FMT_H2>(a, grid, s) : launch_h2q_fmt<FMT_BF16>(a, grid, s);
 }

@@ -141,10 +141,16 @@ int launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     UNI_REQUIRE(a.C % 8 == 0 && a.C % a.G == 0 && a.ldx % 4 == 0, "gn_apply: C=%d G=%d ldx=%d", a.C, a.G, a.ldx);
     if (a.outB) UNI_REQUIRE(a.ldb % 8 == 0 && ((uintptr_t)a.outB & 15) == 0, "gn_apply: outB alignment");
     if (a.outUp) UNI_REQUIRE(a.ldu % 8 == 0 && ((uintptr_t)a.outUp & 15) == 0 && a.W > 0, "gn_apply: outUp alignment");
-    long total = (long)a.M * (a.C / 8);
-    int grid = (int)((total + 255) / 256);
+    // every block first derives the C scale / shift pairs from the group sums (fp64 divide + sqrt per channel), so a block should
+    // then stream several rows: ~4 float4-pairs per thread (measured best of 1 / 4 / 8 / 16), at least ~8 blocks per CU over the whole batch
+    const long total = (long)a.M * (a.C / 8);
+    const int nb = a.B > 0 ? a.B : 1;
+    static const int per = getenv("UNI_GN_PER") ? atoi(getenv("UNI_GN_PER")) : 4;
+    long grid = (total + 256L * per - 1) / (256L * per);
+    const long min_grid = (2048 + nb - 1) / nb;
+    if (grid < min_grid) grid = min_grid < (total + 255) / 256 ? min_grid : (total + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid, a.B > 0 ? a.B : 1), dim3(256), 2 * a.C * sizeof(float), s, a);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)grid, nb), dim3(256), 2 * a.C * sizeof(float), s, a);
     return 0;
 }
 
