@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     const int q2 = FMT == FMT_H2 ? 4 + 2 * fh : 4 + fh, q3 = FMT == FMT_H2 ? 5 + 2 * fh : 6 + fh;
     const int a_rd = (grp * 64 + fr) * ROWB, b_rd = 2 * HALF + (wc * 32 + fr) * ROWB;
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    if (lds0 != 0) __builtin_trap();                 // the stage toggle below XORs bit 16 of the addresses: the dynamic LDS block must start at 0
     int ra4[4] = {lds0 + a_rd + ((q0 ^ sw) << 4), lds0 + a_rd + ((q1 ^ sw) << 4), lds0 + a_rd + ((q2 ^ sw) << 4), lds0 + a_rd + ((q3 ^ sw) << 4)};
     int rb4[4] = {lds0 + b_rd + ((q0 ^ sw) << 4), lds0 + b_rd + ((q1 ^ sw) << 4), lds0 + b_rd + ((q2 ^ sw) << 4), lds0 + b_rd + ((q3 ^ sw) << 4)};
 #define Q_LDS(addr, off) (*reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((size_t)((addr) + (off))))
