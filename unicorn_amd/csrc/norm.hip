@@ -482,14 +482,17 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
     auto reduce16 = [&](const float (&part)[16], float (&tot)[16]) __attribute__((always_inline)) {
         const float t = wave_scatter_sum(part);
         if ((lane & 3) == 0) red[wv * 16 + (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1))] = t;
-        __syncthreads();
+        // a strip that is ONE wave (C <= 256) needs no block barrier: the strips of a block are independent
+        if (wps == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
             float t2 = 0.f;
             for (int w_ = 0; w_ < wps; ++w_) t2 += red[(sl * wps + w_) * 16 + o];     // fixed order: deterministic
             tot[o] = t2;
         }
-        __syncthreads();
+        if (wps == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
     };
 #pragma unroll 1
     for (int it = 0; it < count; ++it) {
@@ -539,8 +542,9 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                     __builtin_amdgcn_sched_barrier(0);           // one 7-tap weight row (28 registers) at a time
                 }
             };
-            // (a register double buffer of the input row -- next row in flight while this one is multiplied -- needs 56 more
-            // registers and spills at the 256 this block size allows; PMC: the waves wait ~50 % of their time on those loads)
+            // PMC: the waves are parked ~50 % of their cycles (loads + barriers), VALU active 23 %.  A register double buffer of the
+            // input row (fits only with ROWS = 2) measured 4-9 % SLOWER, 3 waves per SIMD likewise: the kernel is not latency-bound
+            // in the simple sense; the load path sustains ~9 TB/s of L2 -> L1 traffic here.
             f32x4 ra[IN];
 #pragma unroll 1
             for (int r = 0; r < 6 + ROWS; ++r) {
