@@ -525,31 +525,39 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                     dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cg * 16, ok ? ix * C * 4 : 0, 0));
                 }
             };
-            auto mac_row = [&](const f32x4 (&src)[IN], int r) __attribute__((always_inline)) {   // input row y-3+r: tap row ky = r - q for output row y+q
+            // Weights: the 7 taps of ONE (input row, output row) pair at a time through a register double buffer -- the reads of the
+            // next pair (from LDS, ~100+ cycles) are issued before the 224 FMAs of this one.  (Letting the compiler hoist them
+            // freely costs 100+ registers; fencing every pair with sched_barrier left the waves parked on lgkmcnt ~50 % of their
+            // cycles.)
+            auto ld_w = [&](f32x4 (&w)[7], int ky) __attribute__((always_inline)) {
+                const float* wrow = wl + (min(max(ky, 0), 6) * 7) * C + cg * 4;
 #pragma unroll
-                for (int q = 0; q < ROWS; ++q) {
-                    if (r - q >= 0 && r - q < 7) {               // wave-uniform
-                        const float* wrow = wl + ((r - q) * 7) * C + cg * 4;
-#pragma unroll
-                        for (int kx = 0; kx < 7; ++kx) {
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + kx * C);
-#pragma unroll
-                            for (int o = 0; o < PX; ++o)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[q][o][e] = fmaf(w[e], src[o + kx][e], acc[q][o][e]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);           // one 7-tap weight row (28 registers) at a time
-                }
+                for (int kx = 0; kx < 7; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(wrow + kx * C);
             };
-            // PMC: the waves are parked ~50 % of their cycles (loads + barriers), VALU active 23 %.  A register double buffer of the
-            // input row (fits only with ROWS = 2) measured 4-9 % SLOWER, 3 waves per SIMD likewise: the kernel is not latency-bound
-            // in the simple sense; the load path sustains ~9 TB/s of L2 -> L1 traffic here.
-            f32x4 ra[IN];
+            auto mac = [&](f32x4 (&a)[PX], const f32x4 (&w)[7], const f32x4 (&src)[IN]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int o = 0; o < PX; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[o][e] = fmaf(w[kx][e], src[o + kx][e], a[o][e]);
+            };
+            f32x4 ra[IN], wa[7], wb[7];
+            ld_w(wa, 0);                                         // pair (r = 0, q = 0): tap row 0
 #pragma unroll 1
-            for (int r = 0; r < 6 + ROWS; ++r) {
+            for (int r = 0; r < 6 + ROWS; ++r) {                 // input row y-3+r feeds output row y+q with tap row ky = r - q
                 load_row(ra, y - 3 + r);
-                mac_row(ra, r);
+#pragma unroll
+                for (int q = 0; q < ROWS; q += 2) {
+                    ld_w(wb, r - (q + 1));                       // next pair: (r, q + 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r - q >= 0 && r - q < 7) mac(acc[q], wa, ra);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ld_w(wa, q + 2 < ROWS ? r - (q + 2) : r + 1); // (r, q + 2), or (r + 1, 0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r - q - 1 >= 0 && r - q - 1 < 7) mac(acc[q + 1], wb, ra);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // LayerNorm per pixel: two-pass (mean, then centred variance), 16 pixels per reduction
@@ -576,19 +584,58 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
             for (int u = 0; u < 16; ++u) rstd[2 * h + (u >> 3)][u & 7] = rsqrtf(tot[u] * invC + p.eps);
         }
         if (active && lane_ok) {
+            // 16-byte stores: a lane owns 4 channels = 8 bytes of hi + 8 of lo (f16x2) or 8 bytes of bf16, and 8-byte stores are
+            // store-issue bound (32 per thread and tile).  Lane pairs (cg, cg ^ 1; CG is even) swap halves through DPP: f16x2 --
+            // the even lane writes the 16 hi bytes of the 8-channel group, the odd lane the 16 lo bytes; bf16 -- the even lane writes
+            // the group of pixel o, the odd lane that of pixel o + 1.  A wave instruction then covers 1 KiB of contiguous output.
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + cg * 4);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cg * 4);
+            const bool odd = cg & 1;
+            auto xor1 = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); };
+            auto norm4 = [&](int q, int o, float (&yv)[4]) __attribute__((always_inline)) {
+                const float m = mean[q][o], rs = rstd[q][o];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[e] = (acc[q][o][e] - m) * rs * g[e] + be[e];
+            };
 #pragma unroll
             for (int q = 0; q < ROWS; ++q) {
-                if (y + q < p.H) {
+                if (y + q >= p.H) continue;
+                const size_t prow = (img0 + (size_t)(y + q) * p.W + x0) * C + (cg & ~1) * 4;    // element index of the lane pair's 8-channel group, pixel x0
+                if (p.b32 == FMT_H2) {
 #pragma unroll
                     for (int o = 0; o < PX; ++o) {
-                        if (x0 + o < p.W) {
-                            const float m = mean[q][o], rs = rstd[q][o];
-                            act_store4(p.out, (img0 + (size_t)(y + q) * p.W + x0 + o) * C + cg * 4, (acc[q][o][0] - m) * rs * g[0] + be[0],
-                                       (acc[q][o][1] - m) * rs * g[1] + be[1], (acc[q][o][2] - m) * rs * g[2] + be[2],
-                                       (acc[q][o][3] - m) * rs * g[3] + be[3], p.b32);
-                        }
+                        float yv[4];
+                        norm4(q, o, yv);
+                        f16x4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { f16 hh, ll; h2_split(yv[e], hh, ll); h[e] = hh; l[e] = ll; }
+                        const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
+                        const unsigned s0 = odd ? hu[0] : lu[0], s1 = odd ? hu[1] : lu[1];
+                        const unsigned r0 = xor1(s0), r1 = xor1(s1);
+                        const u32x4 ov = odd ? u32x4{r0, r1, lu[0], lu[1]} : u32x4{hu[0], hu[1], r0, r1};
+                        if (x0 + o < p.W)
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + (prow + (size_t)o * C) * 4 + (odd ? 16 : 0)) = ov;
+                    }
+                } else if (p.b32 == FMT_BF16) {
+#pragma unroll
+                    for (int o = 0; o < PX; o += 2) {
+                        float y0[4], y1[4];
+                        norm4(q, o, y0);
+                        norm4(q, o + 1, y1);
+                        const bf16x4 b0 = {(bf16)y0[0], (bf16)y0[1], (bf16)y0[2], (bf16)y0[3]}, b1 = {(bf16)y1[0], (bf16)y1[1], (bf16)y1[2], (bf16)y1[3]};
+                        const u32x2 u0 = __builtin_bit_cast(u32x2, b0), u1 = __builtin_bit_cast(u32x2, b1);
+                        const unsigned s0 = odd ? u0[0] : u1[0], s1 = odd ? u0[1] : u1[1];
+                        const unsigned r0 = xor1(s0), r1 = xor1(s1);
+                        const u32x4 ov = odd ? u32x4{r0, r1, u1[0], u1[1]} : u32x4{u0[0], u0[1], r0, r1};
+                        const int oo = o + (odd ? 1 : 0);
+                        if (x0 + oo < p.W) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.out) + prow + (size_t)oo * C) = ov;
+                    }
+                } else {
+#pragma unroll
+                    for (int o = 0; o < PX; ++o) {
+                        float yv[4];
+                        norm4(q, o, yv);
+                        if (x0 + o < p.W) act_store4(p.out, (img0 + (size_t)(y + q) * p.W + x0 + o) * C + cg * 4, yv[0], yv[1], yv[2], yv[3], p.b32);
                     }
                 }
             }
@@ -615,10 +662,10 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
         // within 160 KB, at least two rounds of work for 256 CUs and a row shorter than 2 GiB / 4
         static const bool no_b = getenv("UNI_DW_NOLDSW") != nullptr;
         if (!no_b && (long)a.W * a.C * 4 < (1L << 30) && (a.C == 192 || a.C == 256 || a.C == 384 || a.C == 512 || a.C == 768)) {
-            // output rows per thread: 4 (4.4 input float4s per output float4 instead of 7) except for C = 768, where its 16 spilled
-            // registers and the 50-row maps (13 groups of 4) cost more than the traffic saves (tools/dwln_bench.py)
+            // output rows per thread: 4 (4.4 input float4s per output float4 instead of 7) where the 128 accumulators leave the
+            // other registers unspilled (C = 256 / 512: one wave per strip), else 2 (tools/dwln_bench.py)
             static const int rows_env = getenv("UNI_DW_ROWS") ? atoi(getenv("UNI_DW_ROWS")) : 0;
-            const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (a.C == 768 ? 2 : 4);
+            const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (a.C == 256 || a.C == 512 ? 4 : 2);
             const int wps = cdiv(CG, 64), Sw = 8 / wps;          // 512 threads: 8 waves
             const size_t ldsw = (size_t)49 * a.C * 4 + (size_t)8 * 16 * 4;
             const int nst = spr * cdiv(a.H, rows) * nb;
