@@ -105,12 +105,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     const int C8 = p.C >> 3;
     const long total = (long)p.M * C8;
     const size_t row0 = (size_t)sb * p.M;                        // first global row of this sample
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    auto src_of = [&](long e) __attribute__((always_inline)) {
+        const int ml = (int)(e / C8);
+        return reinterpret_cast<const float4*>(p.x + (row0 + ml) * (size_t)p.ldx + (int)(e - (long)ml * C8) * 8);
+    };
+    auto process = [&](long e, float4 a, float4 b) __attribute__((always_inline)) {
         const int ml = (int)(e / C8);                            // row within the sample
         const size_t m = row0 + ml;
         int c = (int)(e - (long)ml * C8) * 8;
-        const float4* xp = reinterpret_cast<const float4*>(p.x + (size_t)m * p.ldx + c);
-        float4 a = xp[0], b = xp[1];
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const float pr = p.prior ? p.prior[m] : 0.f;
 #pragma unroll
@@ -134,6 +136,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
             act_store8(p.outUp, u + W2 * p.ldu, v, p.b32);
             act_store8(p.outUp, u + W2 * p.ldu + p.ldu, v, p.b32);
         }
+    };
+    // two items per trip with both loads issued first (the stores of one item otherwise fence the loads of the next: the output
+    // pointers may alias the input for all the compiler knows)
+    const long stride = (long)gridDim.x * blockDim.x;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; e + stride < total; e += 2 * stride) {
+        const float4* x0 = src_of(e);
+        const float4* x1 = src_of(e + stride);
+        const float4 a0 = x0[0], b0 = x0[1], a1 = x1[0], b1 = x1[1];
+        process(e, a0, b0);
+        process(e + stride, a1, b1);
+    }
+    if (e < total) {
+        const float4* x0 = src_of(e);
+        process(e, x0[0], x0[1]);
     }
 }
 
