@@ -778,6 +778,19 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     static const bool no_fork = getenv("UNI_NO_FORK") != nullptr;     // A/B switch
     const bool fork = c->aux[0] && c->aux[1] && !c->prof_on && !no_fork;   // serialised while event-profiling so per-kernel times are not inflated by overlap
     hipStream_t s_main = s;
+    // an error inside the forked region must not leave the auxiliary streams unjoined (the caller's stream would otherwise race the
+    // levels still in flight): RUN joins them before it returns
+#undef RUN
+#define RUN(expr)                                                                              \
+    do {                                                                                       \
+        int _rc = (expr);                                                                      \
+        if (_rc || c->ws_overflow) {                                                           \
+            if (fork)                                                                          \
+                for (int _i = 0; _i < 2; ++_i)                                                 \
+                    if (hipEventRecord(c->ev_join[_i], c->aux[_i]) == hipSuccess) (void)hipStreamWaitEvent(s_main, c->ev_join[_i], 0); \
+            return _rc ? _rc : -3;                                                             \
+        }                                                                                      \
+    } while (0)
     if (fork) {
         UNI_CHECK_HIP(hipEventRecord(c->ev_fork, s_main));
         for (int i = 0; i < 2; ++i) UNI_CHECK_HIP(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
@@ -860,6 +873,8 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         }
         c->ws_off = lvl_base + 3 * slice_bytes;
     }
+#undef RUN
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; if (c->ws_overflow) return -3; } while (0)
     if (!raw) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, HWk[0], Wk[0], HWk[1], Wk[1], HWk[2], Wk[2], nch, s, B); }));
     if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162 (depends on the FPN maps only: once per IMAGE)
         c->nb = Bi;
