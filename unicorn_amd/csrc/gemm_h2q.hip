@@ -12,8 +12,9 @@
 // matrix pipe never waits for LDS.  The DMA stream runs continuously over the K steps AND over the tiles of the persistent block,
 // ~2 steps ahead in two 64-KiB stages, drained by ONE counted `s_waitcnt vmcnt(6)` per K step (three half-tiles stay in flight
 // across every barrier, raw `s_barrier` only):
-//      half-tile:   B0(S+1)   A0(S+2)   B1(S+2)   A1(S+2)       requested in phase 1 / 2 / 3 / 4 of step S -- each ONE phase after
-//      last read:   p1(S-1)   p1(S)     p2(S)     p3(S)         the last read of the slot it overwrites (reads are retired with
+//      half-tile:   B0(S+1)   A0(S+2)   B1(S+2)   A1(S+2)       requested in phase 2 / 2 / 3 / 4 of step S (phase 1 carries the 12 fragment
+//      last read:   p1(S-1)   p1(S)     p2(S)     p3(S)         reads of A0 + B0 and no request) -- each at least ONE phase after the
+// last read of the slot it overwrites (reads are retired with
 // lgkmcnt(0) before the barrier that ends their phase); after the wait in phase 4 every half-tile of step S+1 has landed for all
 // waves once both groups have passed their next barrier, i.e. before anybody's phase 1 of step S+1.
 // Epilogue = gemm_h2p.hip's (bias, activation, residual, fp32 / operand-format outputs through a per-wave 4-KiB
@@ -257,8 +258,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
             {   // phase 1
-                Q_LD_A(0); Q_LD_B(0);
-                if (!(p.dbg & 1)) { Q_FUT(1); issueB(0, par ^ 1, fk, fb); }
+                Q_LD_A(0); Q_LD_B(0);                 // 12 reads: no DMA request in this phase
                 Q_WAIT_LDS();
                 phase_barrier();
                 if (!(p.dbg & 2)) { Q_MFMA(0, 0); }
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
             }
             {   // phase 2
                 Q_LD_B(1);
+                if (!(p.dbg & 1)) { Q_FUT(1); issueB(0, par ^ 1, fk, fb); }     // B0(S+1) first: it is the oldest request the phase-4 wait must retire
                 if (!(p.dbg & 1)) { Q_FUT(2); issueA(0, par, fk, fa); }
                 Q_WAIT_LDS();
                 phase_barrier();
