@@ -7,13 +7,13 @@
 // 64 x 32 quadrant of the wave tile each:
 //      phase 1: reads A0 + B0, quadrant (A0, B0)        phase 3: reads A1, quadrant (A1, B1)
 //      phase 2: reads B1,      quadrant (A0, B1)        phase 4: (B0 kept), quadrant (A1, B0)
-// A phase is [ds_reads + one half-tile of LDS-DMA] | barrier | [12 MFMAs] | barrier, and the second wave group runs ONE BARRIER
+// A phase is [ds_reads and / or two half-tiles of LDS-DMA] | barrier | [12 MFMAs] | barrier, and the second wave group runs ONE BARRIER
 // BEHIND the first: while one group issues its MFMAs, the other one (same SIMDs) reads fragments and requests DMA, so the
 // matrix pipe never waits for LDS.  The DMA stream runs continuously over the K steps AND over the tiles of the persistent block,
 // ~2 steps ahead in two 64-KiB stages, drained by ONE counted `s_waitcnt vmcnt(6)` per K step (three half-tiles stay in flight
 // across every barrier, raw `s_barrier` only):
-//      half-tile:   B0(S+1)   A0(S+2)   B1(S+2)   A1(S+2)       requested in phase 2 / 2 / 3 / 4 of step S (phase 1 carries the 12 fragment
-//      last read:   p1(S-1)   p1(S)     p2(S)     p3(S)         reads of A0 + B0 and no request) -- each at least ONE phase after the
+//      half-tile:   B0(S+1)   A0(S+2)   B1(S+2)   A1(S+2)       requested in phase 2 / 2 / 4 / 4 of step S (phases 1 and 3 carry the 12 + 8
+//      last read:   p1(S-1)   p1(S)     p2(S)     p3(S)         fragment reads of A0 + B0 / A1 and no request) -- each at least ONE phase after the
 // last read of the slot it overwrites (reads are retired with
 // lgkmcnt(0) before the barrier that ends their phase); after the wait in phase 4 every half-tile of step S+1 has landed for all
 // waves once both groups have passed their next barrier, i.e. before anybody's phase 1 of step S+1.
@@ -275,14 +275,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
             }
             {   // phase 3
                 Q_LD_A(1);
-                if (!(p.dbg & 1)) { Q_FUT(2); issueB(1, par, fk, fb); }
                 Q_WAIT_LDS();
                 phase_barrier();
                 if (!(p.dbg & 2)) { Q_MFMA(1, 1); }
                 phase_barrier();
             }
             {   // phase 4 (B0 is still in registers)
-                if (!(p.dbg & 1)) { Q_FUT(2); issueA(1, par, fk, fa); }
+                if (!(p.dbg & 1)) { Q_FUT(2); issueB(1, par, fk, fb); issueA(1, par, fk, fa); }
                 Q_WAIT_VM(6);
                 Q_WAIT_LDS();
                 phase_barrier();
