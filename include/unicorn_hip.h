@@ -123,7 +123,9 @@ int uni_msda_fwd(const float* value, const int64_t* spatial_shapes, const int64_
                  int L, int P, uni_stream_t stream);
 /* e_ref [R,128], e_cur [Q,128] fp32 row-major (NHWC embedding maps), values [K,R] -> out [K,Q].
  * precision 0 = exact fp32 MFMA, 1 = fp32-equivalent bf16x3 split (6 bf16 MFMAs per product), 2 = fp32-equivalent f16x2 split
- * (3 f16 MFMAs per product; operands must lie inside the f16 range, |x| < 65504 / log2 e).  workspace: device scratch of >= uni_corr_workspace_bytes bytes. */
+ * (3 f16 MFMAs per product; operands must lie inside the f16 range, |x| < 65504 / log2 e), 3 = the reference DRIVER's arithmetic
+ * class (unicorn_sot.py:95-100 casts keys, queries, values to fp16): f16-rounded operands, one MFMA per product, f16-rounded scores
+ * (not the `.half()` of the normalised softmax).  workspace: device scratch of >= uni_corr_workspace_bytes bytes. */
 size_t uni_corr_workspace_bytes(int R, int Q, int K);
 int uni_corr_softmax_pv(const float* e_ref, const float* e_cur, const float* values, float* out, int R, int Q, int D,
                         int K, int precision, void* workspace, size_t workspace_bytes, uni_stream_t stream);

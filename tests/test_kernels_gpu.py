@@ -360,6 +360,23 @@ def test_corr_split_matches_fp32_mfma(L):
     assert e2 < max(4 * e0, 3e-6), (e0, e2)     # 22 operand bits instead of 24
 
 
+def test_corr_fp16_single_pass_mode(L):
+    """precision 3 = the reference driver's fp16 arithmetic class (unicorn_sot.py:95-100) against the oracle's emulation of those
+    casts; it must sit closer to that than to the fp32 definition when the logits are large enough for the casts to matter."""
+    from unicorn_amd.ops import corr_softmax_pv
+    g = torch.Generator().manual_seed(21)
+    R, Q = 4000, 1500
+    er = torch.randn(128, R, generator=g) * 0.9
+    ec = torch.randn(128, Q, generator=g) * 0.9
+    v = torch.rand(3, R, generator=g)
+    ref16 = uo.correlation_propagate(er, ec, v, half=True)
+    ref32 = uo.correlation_propagate(er, ec, v)
+    out = corr_softmax_pv(er.cuda(), ec.cuda(), v.cuda(), precision=3).cpu()
+    e16, e32 = (out - ref16).abs(), (out - ref32).abs()
+    assert e16.max() < 1e-3 and e16.mean() < 1.5e-4, (e16.max(), e16.mean())    # rest: the un-reproduced trans.half() + summation order (CPU emulation: 3e-4 / 6e-5)
+    assert e16.mean() < 0.5 * e32.mean(), (e16.mean(), e32.mean())
+
+
 def test_corr_spiked_rescale(L):
     """force the online-softmax rescale branch: one reference row dominates late in the stream"""
     from unicorn_amd.ops import corr_softmax_pv

@@ -348,7 +348,10 @@ __device__ __forceinline__ void split2h(const float (&x)[8], f16x8& h, f16x8& l)
     }
 }
 
-template <int KV, int NWV>
+// H1 = the reference driver's own arithmetic class (unicorn_sot.py:95-100 casts keys, queries and values to fp16): operands rounded to
+// f16 (the hi halves only), ONE MFMA per product, scores rounded to f16 before the softmax.  (The driver's `trans.half()` rounding of
+// the NORMALISED softmax needs the final row sums, i.e. a second pass, and is not reproduced: probabilities stay fp32.)
+template <int KV, int NWV, bool H1 = false>
 __global__ __launch_bounds__(64 * NWV) void corr_h2_kernel(const float* __restrict__ eref, const float* __restrict__ ecur,
                                                       const float* __restrict__ v, float* __restrict__ out,
                                                       float* __restrict__ ws, int R, int Q, int K, int nsplit,
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(64 * NWV) void corr_h2_kernel(const float* __restri
     for (int c = 0; c < 8; ++c) {
         const f32x4* src = reinterpret_cast<const f32x4*>(ecur + (size_t)qc * CD + 16 * c + 8 * fh);
         const f32x4 t0 = src[0], t1 = src[1];
-        constexpr float L2E = 1.4426950408889634f;
+        constexpr float L2E = H1 ? 1.f : 1.4426950408889634f;    // H1: natural domain, the f16-rounded score is scaled afterwards
         const float x[8] = {t0[0] * L2E, t0[1] * L2E, t0[2] * L2E, t0[3] * L2E, t1[0] * L2E, t1[1] * L2E, t1[2] * L2E, t1[3] * L2E};
         split2h(x, qh[c], ql[c]);
     }
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(64 * NWV) void corr_h2_kernel(const float* __restri
         }
         const int k = tid >> 5, r = r0 + (tid & 31);
         gv = (k < K && k < KV && r < R) ? v[(size_t)k * R + r] : 0.f;
+        if (H1) gv = (float)(f16)gv;
     };
     auto sstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -424,12 +428,12 @@ __global__ __launch_bounds__(64 * NWV) void corr_h2_kernel(const float* __restri
             const int off = ((2 * c + fh) ^ (fr & 15)) << 3;
             const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + off);
             const f16x8 al = *reinterpret_cast<const f16x8*>(arow + PLANE + off);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc2, 0, 0, 0);
+            if (!H1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc2, 0, 0, 0);
+            if (!H1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc2, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+        for (int r = 0; r < 16; ++r) acc[r] = H1 ? (float)(f16)acc[r] * 1.4426950408889634f : acc[r] + acc2[r];
         const int r0 = r_begin + t * TR;
         float sc[16], tmax = -INFINITY;
         if (r0 + TR <= r_end) {
@@ -557,7 +561,11 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
     const int ns = pick_nsplit(R, Q, precision);
     int rps = cdiv(cdiv(R, ns), TR) * TR;
     const int ns_eff = cdiv(R, rps);   // every split non-empty
-    if (precision == 2) {
+    if (precision == 3) {
+        size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
+        hipLaunchKernelGGL((corr_h2_kernel<KV, 8, true>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
+                           Q, K, ns_eff, rps);
+    } else if (precision == 2) {
         size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
         hipLaunchKernelGGL((corr_h2_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
                            Q, K, ns_eff, rps);
@@ -586,7 +594,7 @@ int launch_corr(const float* eref, const float* ecur, const float* v, float* out
                 int precision, void* workspace, size_t ws_bytes, hipStream_t s) {
     UNI_REQUIRE(D == CD, "corr: embedding dim %d unsupported (128)", D);
     UNI_REQUIRE(R > 0 && Q > 0 && K > 0, "corr: empty problem R=%d Q=%d K=%d", R, Q, K);
-    UNI_REQUIRE(precision >= 0 && precision <= 2, "corr: precision %d not implemented (0 = fp32 MFMA, 1 = bf16x3 split, 2 = f16x2 split)", precision);
+    UNI_REQUIRE(precision >= 0 && precision <= 3, "corr: precision %d not implemented (0 = fp32 MFMA, 1 = bf16x3 split, 2 = f16x2 split, 3 = fp16 single pass)", precision);
     UNI_REQUIRE(ws_bytes >= corr_workspace_bytes(R, Q, K), "corr: workspace too small");
     UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
     float* ws = reinterpret_cast<float*>(workspace);

@@ -48,7 +48,9 @@ def corr_softmax_pv(embed_ref, embed_cur, values, precision=0):
     == values @ softmax(embed_ref^T @ embed_cur, dim=0)   (unicorn_sot.py:95-100)
     precision 0: exact fp32 MFMA; 1: fp32-equivalent "bf16x3" (operands split exactly into three bf16 pieces, six fp32-exact
     partial products accumulated in fp32; error at the fp32 rounding level, 2.7x less MFMA time); 2: fp32-equivalent "f16x2"
-    (hi + lo f16 halves, three products: half the MFMA time of bf16x3, same error class for embeddings inside the f16 range)"""
+    (hi + lo f16 halves, three products: half the MFMA time of bf16x3, same error class for embeddings inside the f16 range);
+    3: the arithmetic class of the reference driver itself, which casts keys / queries / values to fp16 (:95-97): f16-rounded
+    operands, one product, f16-rounded scores (the `.half()` of the normalised softmax is not reproduced).  The trackers keep 2."""
     _need_cuda(embed_ref, embed_cur, values)
     er = embed_ref.float().t().contiguous()     # (HW, C) row-major
     ec = embed_cur.float().t().contiguous()
