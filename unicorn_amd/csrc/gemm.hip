@@ -390,7 +390,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     // 188 forces it, UNI_NO_H2Q = A/B switch back to the kernels below)
     {
         static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;
-        const bool rounds = b44 >= 384 || (b44 >= 180 && b44 <= 256);
+        const bool rounds = b44 >= 384 || (b44 >= 180 && (double)b44 / (cdiv((int)b44, 256) * 256.0) >= 0.7);
         if (cfg == 188 || (a.force_cfg % 1000 == 0 && !no_q && a.N > 64 && util44 >= 0.74 && rounds && a.epi && gemm_h2q_supported(a))) {
             if (!gemm_h2q_supported(a)) { uni_set_error("gemm: ping-pong variant does not support this problem"); return -1; }
             return launch_gemm_h2q(a, s);

@@ -250,8 +250,9 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
         else if (util44 >= 0.74 && b44 >= 384 && a.epi) cfg = 44;
-        // one (nearly) full round of the persistent ping-pong kernel beats 128 x 128 tiles at 2 blocks per CU
-        else if (util44 >= 0.74 && a.epi && b44 >= 180 && b44 <= 256 && gemm_h2q_supported(a)) cfg = 44;
+        // rounds of the persistent ping-pong kernel that are >= 70 % full beat 128 x 128 tiles at 2 blocks per CU (16000 x 1536 x 6144:
+        // 378 tiles = 1.48 rounds, 794 vs 905 us)
+        else if (util44 >= 0.74 && a.epi && b44 >= 180 && (double)b44 / (cdiv((int)b44, 256) * 256.0) >= 0.7 && gemm_h2q_supported(a)) cfg = 44;
         else if (b22 >= 400) cfg = 22;
         else if (conv) cfg = b12 >= 400 ? 12 : 11;
         else cfg = b21 >= 400 ? 21 : 11;
