@@ -41,6 +41,40 @@ def test_pack_weight_matches_numpy():
     assert not out[5:].any() and not out[:, 144:].any()
 
 
+def test_pack_weight_h2_matches_numpy():
+    """The host packer of the f16x2 operand format (the headline precision): per 8 consecutive k a 32-byte group
+    [8 x hi][8 x lo] with hi = f16(x * scale), lo = f16(x * scale - hi), one power-of-two scale per tensor that puts max |w|
+    into [2^14, 2^15); k = (ky * KW + kx) * Cin + c; rows / columns beyond N / K are zero."""
+    from unicorn_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    N, Cin, k = 5, 16, 3
+    w = torch.randn(N, Cin, k, k, generator=g) * 0.03
+    w[0, 0, 0, 0] = 0.0
+    w[1, 2, 1, 1] = 1e-7                                   # its lo half is an f16 subnormal / zero: must not blow up
+    K = Cin * k * k
+    Npad, Kpad = 256, (K + 63) // 64 * 64
+    out = np.zeros((Npad, Kpad), dtype=np.uint32)
+    wc = np.ascontiguousarray(w.numpy())
+    sc = C.c_float(0)
+    assert lib.uni_pack_weight_h2(wc.ctypes.data_as(C.c_void_p), N, Cin, k, k, out.ctypes.data_as(C.c_void_p), C.byref(sc)) == 0
+    inv = sc.value                                         # the accumulator multiplier = 1 / scale
+    scale = 1.0 / inv
+    assert np.log2(scale) == round(np.log2(scale)) and 2.0 ** 14 <= float(w.abs().max()) * scale < 2.0 ** 15
+    x = (w.permute(0, 2, 3, 1).reshape(N, K).numpy().astype(np.float32) * np.float32(scale))
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    halves = out.view(np.uint16).reshape(Npad, Kpad // 8, 16)      # [row][group of 8 k][8 hi | 8 lo]
+    got_hi = halves[:N, :, :8].reshape(N, -1)[:, :K].view(np.float16)
+    got_lo = halves[:N, :, 8:].reshape(N, -1)[:, :K].view(np.float16)
+    assert np.array_equal(got_hi.view(np.uint16), hi.view(np.uint16))
+    assert np.array_equal(got_lo.view(np.uint16), lo.view(np.uint16))
+    rec = (got_hi.astype(np.float64) + got_lo.astype(np.float64)) * inv
+    ref = w.permute(0, 2, 3, 1).reshape(N, K).numpy().astype(np.float64)
+    assert np.abs(rec - ref).max() <= np.abs(ref).max() * 2.0 ** -21
+    assert not out[N:].any() and not halves[:N].reshape(N, -1, 16)[:, (K + 7) // 8:].any()
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_fails_loudly_without_gpu():
     from unicorn_amd import _lib
