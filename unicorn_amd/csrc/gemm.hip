@@ -391,7 +391,11 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     {
         static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;
         const bool rounds = b44 >= 384 || (b44 >= 180 && (double)b44 / (cdiv((int)b44, 256) * 256.0) >= 0.7);
-        if (cfg == 188 || (a.force_cfg % 1000 == 0 && !no_q && a.N > 64 && util44 >= 0.74 && rounds && a.epi && gemm_h2q_supported(a))) {
+        // measured per shape against the kernels below (profiles/r02e_bf16_gemm_shapes.txt): with ONE MFMA per product the 8-MFMA phases are
+        // shorter than the LDS / DMA phases, so the schedule only wins where the K loop is long and the A operand streams plainly:
+        // plain GEMMs with K >= 1024 (-5..-15 %); implicit GEMMs (+3..10 %) and K <= 768 layers (0..+8 %) stay where they were
+        const bool pays = !conv && !a.stats && a.K >= 1024;
+        if (cfg == 188 || (a.force_cfg % 1000 == 0 && !no_q && pays && a.N > 64 && util44 >= 0.74 && rounds && a.epi && gemm_h2q_supported(a))) {
             if (!gemm_h2q_supported(a)) { uni_set_error("gemm: ping-pong variant does not support this problem"); return -1; }
             return launch_gemm_h2q(a, s);
         }
