@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--batch", type=int, default=16, help="frames of the stream processed per step (time-batched: the SOT step of a "
                     "frame depends only on the cached reference frame, unicorn_sot.py:78-108, so consecutive frames are independent)")
-    ap.add_argument("--corr-precision", type=int, default=2, choices=[0, 1, 2],
-                    help="0 = fp32 MFMA correlation, 1 = fp32-equivalent bf16x3 split, 2 = fp32-equivalent f16x2 split (default)")
+    ap.add_argument("--corr-precision", type=int, default=2, choices=[0, 1, 2, 3],
+                    help="0 = fp32 MFMA correlation, 1 = fp32-equivalent bf16x3 split, 2 = fp32-equivalent f16x2 split (default), "
+                         "3 = the reference driver's fp16 arithmetic class (not a parity mode)")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline AND in-run parity)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (no modes / configs sub-results)")
