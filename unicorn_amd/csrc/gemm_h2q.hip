@@ -22,9 +22,7 @@
 #include "kernels.h"
 #include "gemm_epi.h"
 
-#define GLDS16R(gptr, lptr)                                                                            \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// GemmArgs::dbg (tools/gemm_h2_bench.py, cfg + 1000 * bits): 1 = no DMA requests, 2 = no MFMAs, 4 = no epilogue stores, 16 = no epilogue
 
 namespace {
 constexpr int NW = 8;
