@@ -205,6 +205,19 @@ int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int 
                 int KW, int stride, int pad, const float* bias, int act, const float* residual, int ldr, float* outF,
                 int ldf, void* outB, int ldb, double* gn_stats, int cpg, int force_cfg, uni_stream_t stream);
 int uni_cast_h2(const float* x, int ldx, void* out, int ldo, int M, int C, uni_stream_t stream);
+/* Fused ConvNeXt MLP of the narrow stages (unicorn/models/backbone/convnext.py:47-54; C in {96, 192, 256}):
+ *     out[m][:] = residual[m][:] + b2 + diag(gamma) W2 . GELU(W1 . a[m][:] + b1)
+ * in one launch with the 4C hidden units kept in registers (csrc/mlp_fused.hip).  uni_mlp_pack lays the nn.Linear weights
+ * w1 [4C][C], w2 [C][4C] (host, fp32; gamma [C] or NULL folded into the rows of w2) out as the f16x2 weight stream the kernel
+ * consumes (uni_mlp_blob_bytes(C) bytes, host; copy it to the device) and returns the two accumulator factors.  a: f16x2 operand
+ * rows (uni_cast_h2 / uni_dwconv7_ln output), b2 must already carry gamma; out may alias residual; out_h2 (optional) receives
+ * an f16x2 copy of the result. */
+size_t uni_mlp_blob_bytes(int C);
+int uni_mlp_pack(const float* w1_host, const float* w2_host, const float* gamma_host, int C, void* blob_host, float* ws1_out,
+                 float* ws2_out);
+int uni_mlp_fused(const void* a_h2, int lda, const void* blob_dev, const float* b1, const float* b2, float ws1, float ws2,
+                  const float* residual, int ldr, float* out, int ldo, void* out_h2, int ldb, int M, int C, int dbg,
+                  uni_stream_t stream);
 int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, float* outF,
                   uint16_t* outB, uni_stream_t stream);
 int uni_dwconv7_ln(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta,

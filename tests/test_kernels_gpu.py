@@ -854,3 +854,83 @@ def test_convnext_block_with_folded_layernorm(L, shape, precision):
     st = stats.cpu().double()
     assert (st[:, 0] - mean).abs().max() < 2e-6 * max(1.0, mean.abs().max().item())
     assert ((st[:, 1] - 1 / torch.sqrt(var + 1e-6)).abs() / (1 / torch.sqrt(var + 1e-6))).max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# fused ConvNeXt MLP (mlp_fused.hip): pwconv1 -> GELU -> pwconv2 (gamma folded) -> + residual in one launch
+# ------------------------------------------------------------------------------------------------
+def mlp_pack(L, w1, w2, gamma):
+    C_ = w1.shape[1]
+    nb = L.lib().uni_mlp_blob_bytes(C_)
+    assert nb == 32 * C_ * C_
+    blob = np.zeros(nb // 2, dtype=np.uint16)
+    a, b = C.c_float(0), C.c_float(0)
+    w1c, w2c, gc = (np.ascontiguousarray(t.float().numpy()) for t in (w1, w2, gamma))
+    L.check(L.lib().uni_mlp_pack(w1c.ctypes.data_as(C.c_void_p), w2c.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), C_,
+                                 blob.ctypes.data_as(C.c_void_p), C.byref(a), C.byref(b)), "mlp_pack")
+    return torch.from_numpy(blob.view(np.int16)).cuda(), a.value, b.value
+
+
+@pytest.mark.parametrize("with_outb", [False, True])
+@pytest.mark.parametrize("C_,M", [(96, 1000), (192, 128), (192, 33000), (256, 4000), (256, 40001), (192, 1), (96, 70000)])
+def test_mlp_fused(L, C_, M, with_outb):
+    """convnext.py:47-54 after the LayerNorm: x + gamma * (W2 GELU(W1 a + b1) + b2), against torch fp64 on the f16x2-decoded
+    operand; ragged M (rows past M are neither read nor written), several tiles per block (M > 128 * 256), in-place residual."""
+    g = torch.Generator().manual_seed(C_ + M)
+    x = torch.randn(M, C_, generator=g) * 1.5
+    w1 = torch.randn(4 * C_, C_, generator=g) * 0.05
+    b1 = torch.randn(4 * C_, generator=g) * 0.2
+    w2 = torch.randn(C_, 4 * C_, generator=g) * 0.05
+    b2 = torch.randn(C_, generator=g) * 0.2
+    gamma = torch.rand(C_, generator=g) + 0.5
+    res = torch.randn(M, C_, generator=g) * 3.0
+    A = cast_h2(L, x.cuda())
+    a_dec = h2_decode(A, M, C_)[0].cpu().double()
+    hid = F.gelu(a_dec @ w1.double().t() + b1.double())
+    ref = res.double() + gamma.double() * (hid @ w2.double().t() + b2.double())
+    blob, ws1, ws2 = mlp_pack(L, w1, w2, gamma)
+    pad = 64                                                 # guard rows behind the output: must stay untouched
+    out = torch.full((M + pad, C_), 777.0, device="cuda")
+    out[:M] = res.cuda()
+    outb = torch.zeros((M + pad, C_), device="cuda", dtype=torch.int32) if with_outb else None
+    L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1.cuda()), L.ptr((gamma * b2).cuda()), ws1, ws2, L.ptr(out), C_,
+                                  L.ptr(out), C_, L.ptr(outb), C_, M, C_, 0, L.stream_ptr()), "mlp_fused")
+    torch.cuda.synchronize()
+    got = out[:M].cpu().double()
+    scale = max(1.0, ref.abs().max().item())
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < 4e-6 * scale, (got - ref).abs().max()
+    assert (out[M:] == 777.0).all()
+    if with_outb:
+        dec = h2_decode(outb[:M], M, C_)[0].cpu().double()
+        assert (dec - got).abs().max() < 1e-6 * scale
+        assert (outb[M:] == 0).all()
+
+
+def test_mlp_fused_matches_unfused_pair(L):
+    """Same block through the two launches the engine used before (uni_gemm_h2: pwconv1 + GELU -> f16x2 hidden, pwconv2 + residual):
+    the fused kernel rounds the hidden activations to the same f16x2 format, so both sit within fp32 round-off of each other."""
+    C_, M = 192, 5000
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, C_, generator=g)
+    w1 = torch.randn(4 * C_, C_, generator=g) * 0.04
+    b1 = torch.randn(4 * C_, generator=g) * 0.1
+    w2 = torch.randn(C_, 4 * C_, generator=g) * 0.04
+    b2 = torch.randn(C_, generator=g) * 0.1
+    gamma = torch.rand(C_, generator=g) + 0.5
+    res = torch.randn(M, C_, generator=g).cuda()
+    A = cast_h2(L, x.cuda())
+    blob, ws1, ws2 = mlp_pack(L, w1, w2, gamma)
+    fused = res.clone()
+    L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1.cuda()), L.ptr((gamma * b2).cuda()), ws1, ws2, L.ptr(fused), C_,
+                                  L.ptr(fused), C_, None, 0, M, C_, 0, L.stream_ptr()), "mlp_fused")
+    W1p, s1 = pack_weight_h2(L, w1.reshape(4 * C_, C_, 1, 1))
+    W2p, s2 = pack_weight_h2(L, (gamma[:, None] * w2).reshape(C_, 4 * C_, 1, 1))
+    hid = torch.zeros((M, 4 * C_), device="cuda", dtype=torch.int32)
+    L.check(L.lib().uni_gemm_h2(L.ptr(A), C_, L.ptr(W1p), s1, M, 4 * C_, M, 1, C_, 1, 1, 1, 0, L.ptr(b1.cuda()), 2, None, 0, None, 0,
+                                L.ptr(hid), 4 * C_, None, 0, 0, L.stream_ptr()), "pw1")
+    two = torch.zeros((M, C_), device="cuda")
+    L.check(L.lib().uni_gemm_h2(L.ptr(hid), 4 * C_, L.ptr(W2p), s2, M, C_, M, 1, 4 * C_, 1, 1, 1, 0, L.ptr((gamma * b2).cuda()), 0, L.ptr(res), C_,
+                                L.ptr(two), C_, None, 0, None, 0, 0, L.stream_ptr()), "pw2")
+    torch.cuda.synchronize()
+    assert (fused - two).abs().max().item() < 3e-6 * max(1.0, two.abs().max().item())

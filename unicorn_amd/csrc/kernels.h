@@ -41,6 +41,25 @@ bool gemm_h2p_supported(const GemmArgs& a);
 int launch_gemm_h2q(const GemmArgs& a, hipStream_t s);    // gemm_h2q.hip: persistent 256x256, two wave groups ping-pong MFMA / LDS phases, counted-vmcnt DMA stream
 bool gemm_h2q_supported(const GemmArgs& a);
 
+// ---------------------------------------------------------------- mlp_fused.hip
+// Fused ConvNeXt MLP (pwconv1 -> GELU -> pwconv2 (gamma folded) -> + residual), f16x2 operands, hidden kept in registers
+struct MlpArgs {
+    const void* A = nullptr; int lda = 0;     // [M][C] f16x2 operand rows (dwconv7 + LayerNorm output)
+    const void* blob = nullptr;               // weight stream of mlp_pack_host (mlp_blob_bytes(C) bytes)
+    const float* b1 = nullptr;                // [4C]
+    const float* b2 = nullptr;                // [C], layer scale folded in
+    float ws1 = 1.f, ws2 = 1.f;               // accumulator factors (1 / power-of-two weight scale)
+    const float* res = nullptr; int ldr = 0;  // fp32 residual rows (may alias out)
+    float* out = nullptr; int ldo = 0;        // fp32 [M][C]
+    void* outB = nullptr; int ldb = 0;        // optional f16x2 copy of the result
+    int M = 0, C = 0;
+    int dbg = 0;                              // ablation switches (tools/mlp_bench.py): 1 no DMA, 2 no MFMA, 4 no stores
+};
+int launch_mlp_fused(const MlpArgs& a, hipStream_t s);
+bool mlp_fused_supported(int C);
+size_t mlp_blob_bytes(int C);
+void mlp_pack_host(const float* w1, const float* w2, const float* gamma, int C, uint16_t* out, float* ws1, float* ws2);
+
 // ---------------------------------------------------------------- norm.hip
 // Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.
 struct LnArgs {

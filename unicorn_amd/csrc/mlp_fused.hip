@@ -1,0 +1,462 @@
+// Fused ConvNeXt MLP for the narrow stages (convnext.py:47-54, Block.forward after the LayerNorm):
+//
+//     out[m][:] = res[m][:] + b2 + W2' . GELU(W1 . a[m][:] + b1)            W2' = diag(gamma) W2, 4C hidden units
+//
+// in ONE launch, "f16x2" operands (hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16, fp32 accumulate; common.h FMT_H2).  The
+// unfused pair (gemm_h2q: pwconv1 + GELU -> hidden tensor -> pwconv2 + residual) spends more time on the 4-byte-per-element hidden
+// tensor than in its K loops when C is small: stage 0 of the large model (M = 1 024 000 rows per 16 frames, C = 192) writes and
+// re-reads 3.1 GB per block and runs at 210 / 262 TFLOP/s-equivalent.  Here the hidden activations never leave the registers:
+//
+//  * 4 waves per block, one per SIMD (512-register budget), each wave OWNS 32 pixel rows of a 128-row tile for both GEMMs.
+//    Lane (fr, fh) = (lane & 31, lane >> 5) holds row fr.  The A operand (32 x C, f16x2) is loaded once per tile straight into
+//    MFMA fragments (C / 2 registers) -- nothing to share between waves, so it never touches LDS.
+//  * GEMM1 (swapped operands: weights as the MFMA "A", pixels as "B") leaves lane (fr, fh) with hidden units 8g + 4fh + e
+//    (g, e < 4) of a 32-unit block = exactly what a B-operand fragment of GEMM2 needs IF the k order inside every group of 16
+//    hidden units is [0-3, 8-11 | 4-7, 12-15]: the host packs W2 with that permutation, so bias + GELU + hi/lo split of the 16
+//    accumulators ARE the GEMM2 operand (the flash-attention P -> PV chaining, with GELU in the place of the softmax).
+//  * Only the weights go through LDS: the host lays W1 / W2 out as a stream of 2 * NH "pieces" (NH = 4C / 32 hidden blocks; a
+//    piece = the 32 x C slab of W1 or the C x 32 slab of W2 of one hidden block, 128 C bytes) in consumption order, each piece
+//    already in its bank-conflict-free LDS image, so the fill is a linear `buffer_load_dwordx4 ... lds` stream into a ring of
+//    3-6 slots, NSLOT - 1 pieces ahead of the MFMAs, one counted `s_waitcnt vmcnt` + one raw `s_barrier` per piece.
+//  * Software pipeline inside a tile: GEMM1 of hidden block h + 1 is issued beside the GELU of block h (VALU under MFMA), then
+//    GEMM2 of block h.  Two accumulator chains in GEMM1 (even / odd k slices), C / 32 chains in GEMM2.
+//
+// Work per 128-row tile and wave: 2 * NH * 3 C / 16 MFMAs; LDS reads 2 x 16 B per 3 MFMAs; DMA 32 C^2 bytes per tile and block
+// (C = 192: 1.18 MB per 55k MFMA cycles = 11 B/clk/CU, half of what the 256 x 256 GEMM tiles stream).
+#include "kernels.h"
+
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+namespace {
+constexpr int MW = 4;                    // waves per block
+constexpr int BMF = 32 * MW;             // rows per tile
+
+template <int C>
+struct Geo {
+    static constexpr int NS = C / 16;                // k slices of the A operand
+    static constexpr int NH = C / 8;                 // hidden blocks of 32 units (4C / 32)
+    static constexpr int NJ = C / 32;                // output column blocks
+    static constexpr int PB = 128 * C;               // bytes per weight piece
+    static constexpr int IPW = C / 32;               // 1-KiB DMA instructions per wave and piece
+    static constexpr int BIAS = 20 * C;              // b1 (4C floats) + b2 (C floats) resident in LDS behind the ring
+    static constexpr int NSLOT = ((163840 - BIAS) / PB) < 6 ? ((163840 - BIAS) / PB) : 6;
+    static constexpr int LDS = NSLOT * PB + BIAS;
+    static constexpr int NP = 2 * NH;                // pieces per tile
+    static constexpr int KW = (NSLOT - 2) * IPW;     // DMA instructions of this wave that may stay in flight behind the piece being waited for
+    static_assert(C % 32 == 0 && NSLOT >= 3 && KW <= 60, "geometry");
+};
+
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define F_LDS(ptr) (*reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(ptr))
+#define F_MFMA(w, a, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0)
+}  // namespace
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// CH = accumulator chains of GEMM1 (2: even / odd k slices; 1 where the registers do not allow the second one)
+template <int C, int CH, bool OUTB, int DBG>
+__global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
+    using G = Geo<C>;
+    constexpr int NS = G::NS, NH = G::NH, NJ = G::NJ, PB = G::PB, IPW = G::IPW, NSLOT = G::NSLOT, NP = G::NP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const int ntiles = (p.M + BMF - 1) / BMF;
+    const int count = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (count == 0) return;
+    const int total = count * NP;                    // pieces this block consumes
+
+    // ---- weight stream: piece P of the block comes from blob + (P % NP) * PB, goes to ring slot P % NSLOT.  Requests past the
+    // block's last piece keep the stream's shape (same vmcnt arithmetic, no branch): their offset lies beyond num_records, so they
+    // write zeros into a slot nobody reads any more.
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.blob), 0, NP * PB, 0x00020000);
+    const int vo_w = lane * 16 + wave * 1024;
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int p_issue = 0, src_q = 0, wr_slot = 0;         // next piece to request: its index, its position in the blob, its slot
+    auto issue_piece_part = [&](auto II) __attribute__((always_inline)) {      // request II of the IPW of the next piece
+        constexpr int i = decltype(II)::value;
+        const int so = (p_issue < total && !(DBG & 1)) ? src_q * PB : 0x40000000;
+        char* dst = smem + wr_slot * PB + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, vo_w, so + i * 4096, 0, 0);
+    };
+    auto issue_piece_done = [&]() __attribute__((always_inline)) {
+        ++p_issue;
+        src_q = src_q + 1 == NP ? 0 : src_q + 1;
+        wr_slot = wr_slot + 1 == NSLOT ? 0 : wr_slot + 1;
+    };
+    auto issue_piece = [&]() __attribute__((always_inline)) {
+        static_for<0, IPW>([&](auto II) __attribute__((always_inline)) { issue_piece_part(II); });
+        issue_piece_done();
+    };
+    int rd_slot = 0;
+    // start of the piece the MFMAs consume next: own DMA share landed -> barrier (everybody's share landed, everybody is done with the
+    // previous piece, whose slot the next request overwrites).  Returns the LDS address of the piece; the caller requests piece
+    // (this + NSLOT - 1) with issue_piece() inside its instruction stream.
+    auto piece_begin = [&]() __attribute__((always_inline)) -> int {
+        wait_vm<G::KW>();
+        raw_barrier();
+        const int base = lds0 + rd_slot * PB;
+        rd_slot = rd_slot + 1 == NSLOT ? 0 : rd_slot + 1;
+        return base;
+    };
+
+    // ---- fragment read offsets (the images are built by mlp_pack_host below)
+    // W1 piece [slice s][row r][4 chunks]: chunk c = 2 fh + hl of (row, slice) sits at c ^ ((r >> 2) & 3)
+    const int o1_hi = fr * 64 + (((2 * fh) ^ ((fr >> 2) & 3)) << 4), o1_lo = fr * 64 + (((2 * fh + 1) ^ ((fr >> 2) & 3)) << 4);
+    // W2 piece [col block j][row r][8 chunks]: chunk c = 4 s + 2 fh + hl sits at c ^ ((r >> 1) & 7)
+    int o2[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) o2[s][hl] = fr * 128 + (((4 * s + 2 * fh + hl) ^ ((fr >> 1) & 7)) << 4);
+
+    const float ws1 = p.ws1, ws2 = p.ws2;
+    // biases: copied once into LDS (behind the ring); lane (fr, fh) reads its 4-column quads b[8 g + 4 fh ..] as broadcast ds_read_b128
+    // (vector-memory loads would sit on the DMA stream's vmcnt, scalar loads need a per-lane select that costs 7 VALU per element)
+    {
+        float* bl = reinterpret_cast<float*>(smem + NSLOT * PB);
+        for (int i = tid; i < 5 * C; i += 64 * MW) bl[i] = i < 4 * C ? p.b1[i] : p.b2[i - 4 * C];
+        __syncthreads();
+    }
+    const int bias_rd = lds0 + NSLOT * PB + 16 * fh;
+#define F_LDSF(addr) (*reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((size_t)(addr)))
+
+    f16x8 Ahi[NS], Alo[NS];
+    f32x16 acc2[NJ];
+    f32x16 acc1[2][CH];
+    f16x8 hf[2][2][2];                               // GEMM2 operand of a hidden block: [block parity][k slice][hi, lo]
+
+    const int lda4 = p.lda * 4;
+    auto load_a = [&](int tile) __attribute__((always_inline)) {
+        const int m0 = tile * BMF;
+        const int rows = min(BMF, p.M - m0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + (size_t)m0 * lda4, 0, rows * lda4, 0x00020000);
+        const int vo = (32 * wave + fr) * lda4 + fh * 32;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            Ahi[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64 * s, 0, 0));
+            Alo[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64 * s + 16, 0, 0));
+        }
+    };
+    // ---- bias + GELU + hi / lo split of the lane's 16 accumulators of a hidden block, cut into 32 sub-steps (2 quads x 4 stages x 4
+    // elements, stage-major inside a quad so the exp / rcp latencies sit between independent elements) that are dealt out one by one
+    // between the MFMAs of the neighbouring GEMM blocks.  Quad q = accumulators 4q .. 4q+3 = hidden units 8q + 4fh + e of the block =
+    // elements 4 (q & 1) .. of the k-slice q >> 1 fragment of GEMM2.  (erfc form of act_fast<ACT_GELU>, common.h.)
+    float gx[4], ge[4], gt[4], gq[4];
+    f32x4 gb;
+    f16 gh, gl;
+    auto gelu_step = [&](auto K, int q, int h, const f32x16 (&a)[CH], f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;        // 0 .. 15 inside the quad
+        constexpr int st = k >> 2, e = k & 3;
+        if constexpr (st == 0) {
+            if constexpr (e == 0) gb = F_LDSF(bias_rd + (32 * h + 8 * q) * 4);
+            float v = a[0][4 * q + e];
+            if (CH == 2) v += a[CH - 1][4 * q + e];
+            gx[e] = fmaf(v, ws1, gb[e]);
+            const float u = fabsf(gx[e]) * 0.84932180028801904f;
+            ge[e] = __builtin_amdgcn_exp2f(-u * u);
+            asm volatile("" : "+v"(gx[e]), "+v"(ge[e]));      // pins: the optimiser must not gather the sub-steps (or pack two elements into v_pk_* ops, slow beside MFMAs)
+        } else if constexpr (st == 1) {
+            gt[e] = __builtin_amdgcn_rcpf(fmaf(fabsf(gx[e]), 0.23164188588f, 1.f));
+            gq[e] = fmaf(fmaf(0.5307027145f, gt[e], -0.7265760135f), gt[e], 0.7107068705f);
+            asm volatile("" : "+v"(gt[e]), "+v"(gq[e]));
+        } else if constexpr (st == 2) {
+            gq[e] = fmaf(fmaf(gq[e], gt[e], -0.142248368f), gt[e], 0.127414796f);
+            ge[e] = gq[e] * gt[e] * ge[e];
+            asm volatile("" : "+v"(ge[e]));
+        } else {
+            const float y = fmaf(-fabsf(gx[e]), ge[e], fmaxf(gx[e], 0.f));
+            const float c = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+            const f16 yh = (f16)c;
+            const f16 yl = (f16)(y - (float)yh);
+            if constexpr ((e & 1) == 0) { gh = yh; gl = yl; }
+            else {                                   // two elements per 32-bit register of the fragment
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+                f16x2v ph = {gh, yh}, pl = {gl, yl};
+                unsigned uh = __builtin_bit_cast(unsigned, ph), ul = __builtin_bit_cast(unsigned, pl);
+                asm volatile("" : "+v"(uh), "+v"(ul));
+                u32x4 dh = __builtin_bit_cast(u32x4, dst[q >> 1][0]), dl = __builtin_bit_cast(u32x4, dst[q >> 1][1]);
+                dh[2 * (q & 1) + (e >> 1)] = uh;
+                dl[2 * (q & 1) + (e >> 1)] = ul;
+                dst[q >> 1][0] = __builtin_bit_cast(f16x8, dh);
+                dst[q >> 1][1] = __builtin_bit_cast(f16x8, dl);
+            }
+        }
+    };
+    // sub-step `i` of the 32 that finish quads (q0, q0 + 1) of hidden block h
+    auto gelu_sub = [&](auto I, int q0, int h, const f32x16 (&a)[CH], f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        gelu_step(std::integral_constant<int, (i & 15)>{}, q0 + (i >> 4), h, a, dst);
+    };
+    // A block of MFMAs as NPAIR pair-steps: two independent accumulators alternate (m(a,t0) m(b,t0) m(a,t1) m(b,t1) m(a,t2) m(b,t2) --
+    // an issue slot between two MFMAs on the SAME accumulator costs ~43 cycles, on different ones ~6), the 4 fragments of the next
+    // pair-step are requested after the second MFMA, one "filler" call follows every MFMA, and sched_barrier(0) pins that order: with
+    // one wave per SIMD the instruction stream IS the schedule.
+    f16x8 wf[2][2][2];                               // [buffer][operand of the pair][hi, lo]
+    auto run_block = [&](auto NPAIR_T, auto&& frag_addr, auto&& mfma, auto&& filler) __attribute__((always_inline)) {
+        constexpr int NPAIR = decltype(NPAIR_T)::value;
+        auto load = [&](auto P) __attribute__((always_inline)) {
+            constexpr int pp = decltype(P)::value;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                wf[pp & 1][w][0] = F_LDS(frag_addr(2 * pp + w, 0));
+                wf[pp & 1][w][1] = F_LDS(frag_addr(2 * pp + w, 1));
+            }
+        };
+        load(std::integral_constant<int, 0>{});
+        static_for<0, NPAIR>([&](auto P) __attribute__((always_inline)) {
+            constexpr int pp = decltype(P)::value;
+            static_for<0, 6>([&](auto Kk) __attribute__((always_inline)) {
+                constexpr int k = decltype(Kk)::value;
+                constexpr int w = k & 1, term = k >> 1;
+                // terms: lo.hi, hi.lo, hi.hi
+                if (!(DBG & 2)) mfma(2 * pp + w, term == 0 ? wf[pp & 1][w][1] : wf[pp & 1][w][0], term);
+                if constexpr (k == 1 && pp + 1 < NPAIR) load(std::integral_constant<int, pp + 1>{});
+                filler(std::integral_constant<int, pp * 6 + k>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+    // sub-steps [i0, i1) of the 32 for MFMA slot `slot` of `nslots`, the first `head` slots left free
+    // GEMM1 of one hidden block: acc (2 chains: even / odd k slices) = W1[32 units][C] . a, fillers = GELU sub-steps + this piece's DMA requests
+    auto block_a = [&](int base, f32x16 (&a)[CH], auto&& sub) __attribute__((always_inline)) {
+        static_assert(CH == 2, "two accumulator chains");
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[c][r] = 0.f;
+        const __attribute__((address_space(3))) char* b_hi = (const __attribute__((address_space(3))) char*)(size_t)(base + o1_hi);
+        const __attribute__((address_space(3))) char* b_lo = (const __attribute__((address_space(3))) char*)(size_t)(base + o1_lo);
+        constexpr int NM = 3 * NS;
+        run_block(std::integral_constant<int, NS / 2>{},
+                  [&](int s, int hl) __attribute__((always_inline)) { return (hl ? b_lo : b_hi) + s * 2048; },
+                  [&](int s, const f16x8& w, int term) __attribute__((always_inline)) { F_MFMA(w, term == 1 ? Alo[s] : Ahi[s], a[s & 1]); },
+                  [&](auto SL) __attribute__((always_inline)) {
+                      constexpr int sl = decltype(SL)::value;
+                      if constexpr (sl * IPW / NM != (sl + 1) * IPW / NM) issue_piece_part(std::integral_constant<int, sl * IPW / NM>{});
+                      static_for<sl * 32 / NM, (sl + 1) * 32 / NM>([&](auto I) __attribute__((always_inline)) { sub(I); });
+                  });
+        issue_piece_done();
+    };
+    // GEMM2 of one hidden block: acc2[j] += W2'[32 j ..][32 units] . hfr; items (k slice s, column block j) in pairs
+    auto block_b = [&](int base, const f16x8 (&hfr)[2][2], auto&& sub, auto HEAD, auto&& extra) __attribute__((always_inline)) {
+        constexpr int NM = 6 * NJ;
+        constexpr int nfill = decltype(HEAD)::value;   // the sub-steps are dealt out over the first nfill slots
+        const __attribute__((address_space(3))) char* b2[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) b2[s][hl] = (const __attribute__((address_space(3))) char*)(size_t)(base + o2[s][hl]);
+        run_block(std::integral_constant<int, NJ>{},
+                  [&](int it, int hl) __attribute__((always_inline)) { return b2[it / NJ][hl] + (it % NJ) * 4096; },
+                  [&](int it, const f16x8& w, int term) __attribute__((always_inline)) { F_MFMA(w, term == 1 ? hfr[it / NJ][1] : hfr[it / NJ][0], acc2[it % NJ]); },
+                  [&](auto SL) __attribute__((always_inline)) {
+                      constexpr int sl = decltype(SL)::value;
+                      if constexpr (sl * IPW / NM != (sl + 1) * IPW / NM) issue_piece_part(std::integral_constant<int, sl * IPW / NM>{});
+                      if constexpr (sl < nfill) static_for<sl * 32 / nfill, (sl + 1) * 32 / nfill>([&](auto I) __attribute__((always_inline)) { sub(I); });
+                      extra(SL);
+                  });
+        issue_piece_done();
+    };
+    auto nosub = [](auto) __attribute__((always_inline)) {};
+
+    // ---- prologue: NSLOT - 1 pieces requested, A of the first tile
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) issue_piece();
+    load_a(blockIdx.x);
+
+#pragma unroll 1
+    for (int t = 0; t < count; ++t) {
+        const int tile = blockIdx.x + t * gridDim.x;
+        const int m0 = tile * BMF;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+        // piece order of a tile (mlp_pack_host): W1_0 | W1_1 W2_0 | W1_2 W2_1 | ... | W1_{NH-1} W2_{NH-2} | W2_{NH-1}
+        // schedule: block A_h = GEMM1(h + 1) beside the second half of GELU(h); block B_h = GEMM2(h) beside the first half of GELU(h + 1)
+        block_a(piece_begin(), acc1[0], nosub);
+        static_for<0, 32>([&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, 0, acc1[0], hf[0]); });
+        constexpr auto FULL = std::integral_constant<int, 6 * NJ>{};
+#pragma unroll 1
+        for (int h = 0; h < NH - 2; h += 2) {        // NH is even: pairs (h, h + 1), then the single block NH - 2 below
+            block_a(piece_begin(), acc1[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, h, acc1[0], hf[0]); });
+            block_b(piece_begin(), hf[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, h + 1, acc1[1], hf[1]); }, FULL, nosub);
+            block_a(piece_begin(), acc1[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, h + 1, acc1[1], hf[1]); });
+            block_b(piece_begin(), hf[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, h + 2, acc1[0], hf[0]); }, FULL, nosub);
+        }
+        block_a(piece_begin(), acc1[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, NH - 2, acc1[0], hf[0]); });
+        block_b(piece_begin(), hf[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, NH - 1, acc1[1], hf[1]); }, FULL, nosub);
+        // the A fragments are dead: their registers take the residual rows (accumulator layout: 16 B of row fr per (j, g)), requested
+        // beside the last GEMM2
+        const int rows = min(BMF, p.M - m0);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res) + (size_t)m0 * p.ldr, 0, rows * p.ldr * 4, 0x00020000);
+        const int vo_r = ((32 * wave + fr) * p.ldr + 4 * fh) * 4;
+        f32x4 rv[NJ][4];
+        // last block: the second half of GELU(NH - 1) must be complete before the k-slice-1 items (second half of the slots), so its
+        // sub-steps are dealt out over the first third; the residual requests follow, one per slot
+        block_b(piece_begin(), hf[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, NH - 1, acc1[1], hf[1]); },
+                std::integral_constant<int, 2 * NJ>{}, [&](auto SL) __attribute__((always_inline)) {
+                    constexpr int sl = decltype(SL)::value;
+                    constexpr int r0 = sl * 4 * NJ / (6 * NJ), r1 = (sl + 1) * 4 * NJ / (6 * NJ);
+                    static_for<r0, r1>([&](auto R) __attribute__((always_inline)) {
+                        constexpr int r = decltype(R)::value;
+                        rv[r / 4][r % 4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo_r + (32 * (r / 4) + 8 * (r % 4)) * 4, 0, 0));
+                    });
+                });
+        // ---- epilogue: out = acc2 * ws2 + b2 + res, lane (fr, fh) owns columns 32 j + 8 g + 4 fh + e of row fr
+        {
+            const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)m0 * p.ldo, 0, rows * p.ldo * 4, 0x00020000);
+            const int vo_o = ((32 * wave + fr) * p.ldo + 4 * fh) * 4;
+            const int row = m0 + 32 * wave + fr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = F_LDSF(bias_rd + (4 * C + 32 * j + 8 * g) * 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc2[j][4 * g + e], ws2, b4[e]) + rv[j][g][e];
+                    if (!(DBG & 4)) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, vo_o + (32 * j + 8 * g) * 4, 0, 0);
+                        if (OUTB && row < p.M) act_store4(p.outB, (size_t)row * p.ldb + 32 * j + 8 * g + 4 * fh, v[0], v[1], v[2], v[3], FMT_H2);
+                    }
+                }
+            }
+        }
+        if (t + 1 < count) load_a(tile + gridDim.x);
+    }
+    wait_vm<0>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: weight stream in consumption order, every piece in its LDS image
+// ------------------------------------------------------------------------------------------------
+// w1 [4C][C], w2 [C][4C] fp32 (nn.Linear layouts of pwconv1 / pwconv2), gamma [C] = layer scale folded into the rows of w2 (may be
+// NULL).  out: mlp_blob_bytes(C) bytes.  *ws1 / *ws2 = the factors the accumulators are multiplied with (1 / power-of-two scale).
+size_t mlp_blob_bytes(int C) { return (size_t)32 * C * C; }
+// C = 384 would need 192 (A) + 192 (output accumulators) registers before anything else: it spills, and a 64-row tile that halves them
+// is DMA-bound (the whole 4.7 MB stream per 64 rows).  Stage 1 of the large model stays on the unfused pair.
+bool mlp_fused_supported(int C) { return C == 96 || C == 192 || C == 256; }
+
+void mlp_pack_host(const float* w1, const float* w2, const float* gamma, int C, uint16_t* out, float* ws1, float* ws2) {
+    const int H4 = 4 * C, NH = C / 8, NS = C / 16, NJ = C / 32, PB = 128 * C;
+    float m1 = 0.f, m2 = 0.f;
+    for (size_t i = 0; i < (size_t)H4 * C; ++i) m1 = std::max(m1, fabsf(w1[i]));
+    for (int n = 0; n < C; ++n)
+        for (int k = 0; k < H4; ++k) m2 = std::max(m2, fabsf((gamma ? gamma[n] : 1.f) * w2[(size_t)n * H4 + k]));
+    const float s1 = h2_weight_scale(m1), s2 = h2_weight_scale(m2);
+    *ws1 = 1.f / s1;
+    *ws2 = 1.f / s2;
+    auto put8 = [](uint16_t* dst, const float* v8, bool lo) {
+        for (int i = 0; i < 8; ++i) {
+            const uint16_t hi = f32_to_f16_host(v8[i]);
+            dst[i] = lo ? f32_to_f16_host(v8[i] - f16_to_f32_host(hi)) : hi;
+        }
+    };
+    auto piece_w1 = [&](int h, uint16_t* dst) {      // [slice][row][4 chunks of 16 B]
+        for (int s = 0; s < NS; ++s)
+            for (int r = 0; r < 32; ++r)
+                for (int pc = 0; pc < 4; ++pc) {
+                    const int c = pc ^ ((r >> 2) & 3), fh = c >> 1, hl = c & 1;
+                    float v8[8];
+                    for (int i = 0; i < 8; ++i) v8[i] = w1[(size_t)(32 * h + r) * C + 16 * s + 8 * fh + i] * s1;
+                    put8(dst + ((size_t)(s * 32 + r) * 4 + pc) * 8, v8, hl);
+                }
+    };
+    auto piece_w2 = [&](int h, uint16_t* dst) {      // [col block][row][8 chunks of 16 B], k order inside 16 hidden units: 0-3 8-11 | 4-7 12-15
+        for (int j = 0; j < NJ; ++j)
+            for (int r = 0; r < 32; ++r)
+                for (int pc = 0; pc < 8; ++pc) {
+                    const int c = pc ^ ((r >> 1) & 7), s = c >> 2, fh = (c >> 1) & 1, hl = c & 1;
+                    const int n = 32 * j + r;
+                    const float gsc = (gamma ? gamma[n] : 1.f) * s2;
+                    float v8[8];
+                    for (int i = 0; i < 8; ++i) {
+                        const int u = 32 * h + 16 * s + (i < 4 ? 4 * fh + i : 4 + 4 * fh + i);
+                        v8[i] = gsc * w2[(size_t)n * H4 + u];
+                    }
+                    put8(dst + ((size_t)(j * 32 + r) * 8 + pc) * 8, v8, hl);
+                }
+    };
+    const size_t pe = (size_t)PB / 2;                // uint16 per piece
+    size_t q = 0;
+    piece_w1(0, out + (q++) * pe);
+    for (int h = 0; h + 1 < NH; ++h) {
+        piece_w1(h + 1, out + (q++) * pe);
+        piece_w2(h, out + (q++) * pe);
+    }
+    piece_w2(NH - 1, out + (q++) * pe);
+}
+
+template <int C, int CH, bool OUTB, int DBG>
+static int launch_mlp_k(const MlpArgs& a, int grid, hipStream_t s) {
+    constexpr int lds = Geo<C>::LDS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, CH, OUTB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            uni_set_error("mlp_fused: cannot reserve %d bytes of LDS", lds);
+            return -1;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mlp_fused_kernel<C, CH, OUTB, DBG>), dim3(grid), dim3(64 * MW), lds, s, a);
+    return 0;
+}
+template <int C, int CH>
+static int launch_mlp_inst(const MlpArgs& a, int grid, hipStream_t s) {
+    if (a.dbg && C == 192 && !a.outB) {     // ablations for tools/mlp_bench.py, C = 192 only
+        switch (a.dbg) {
+            case 1: return launch_mlp_k<192, 2, false, 1>(a, grid, s);
+            case 2: return launch_mlp_k<192, 2, false, 2>(a, grid, s);
+            case 3: return launch_mlp_k<192, 2, false, 3>(a, grid, s);
+            case 4: return launch_mlp_k<192, 2, false, 4>(a, grid, s);
+            default: break;
+        }
+    }
+    return a.outB ? launch_mlp_k<C, CH, true, 0>(a, grid, s) : launch_mlp_k<C, CH, false, 0>(a, grid, s);
+}
+
+int launch_mlp_fused(const MlpArgs& a, hipStream_t s) {
+    UNI_REQUIRE(mlp_fused_supported(a.C), "mlp_fused: C=%d unsupported", a.C);
+    UNI_REQUIRE(a.A && a.blob && a.b1 && a.b2 && a.res && a.out && a.M > 0, "mlp_fused: NULL argument");
+    UNI_REQUIRE(a.lda % 8 == 0 && a.ldr % 4 == 0 && a.ldo % 4 == 0 && (!a.outB || a.ldb % 8 == 0), "mlp_fused: lda=%d ldr=%d ldo=%d ldb=%d", a.lda, a.ldr, a.ldo, a.ldb);
+    UNI_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.blob & 15) == 0 && ((uintptr_t)a.res & 15) == 0 && ((uintptr_t)a.out & 15) == 0 &&
+                ((uintptr_t)a.b1 & 3) == 0 && ((uintptr_t)a.b2 & 3) == 0, "mlp_fused: unaligned pointer");
+    UNI_REQUIRE((long)BMF * a.lda * 4 < (1L << 31) && (long)BMF * a.ldo * 4 < (1L << 31), "mlp_fused: row stride too large");
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ntiles = cdiv(a.M, BMF);
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    switch (a.C) {
+        case 96: return launch_mlp_inst<96, 2>(a, grid, s);
+        case 192: return launch_mlp_inst<192, 2>(a, grid, s);
+        default: return launch_mlp_inst<256, 2>(a, grid, s);
+    }
+}
