@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="unicorn_track_large")
-    ap.add_argument("--task", default="sot", choices=["sot", "mot", "vos"])
+    ap.add_argument("--task", default="sot", choices=["sot", "mot", "vos", "mix"],
+                    help="mix = BASELINE.json configs[4]: rank r runs the MOT loop (evaluate_omni) if r < N/2, the SOT step otherwise")
+    ap.add_argument("--gather-every", type=int, default=1, help="steps between the in-run RCCL gathers of the result rows (N > 1)")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16", "fp32"])
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1280)
@@ -68,6 +70,34 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def rank_task(task, model, rank, world):
+    """BASELINE.json configs[4] ("MOT+SOT mix"): with --task mix the first half of the ranks run the MOT loop (evaluate_omni on the
+    MOT17-style model, num_classes = 1), the second half the SOT step; a single rank runs SOT.  -> (task, model) of this rank."""
+    if task != "mix":
+        return task, model
+    t = "mot" if rank < world // 2 else "sot"
+    if t == "mot" and model == "unicorn_track_large":
+        model = "unicorn_track_large_mot_challenge"
+    return t, model
+
+
+def make_gather(rank, stat):
+    """in-run result gather of one step: two RCCL (gloo in the CPU tests) all_gathers of fixed-stride rows (unicorn_amd/parallel.py)"""
+    from unicorn_amd.parallel import gather_result_rows
+
+    def gather(streams):
+        import torch
+        rows = torch.cat([s_.last_rows for s_ in streams], 0).clone()
+        rows[:, 0] = rank
+        table = gather_result_rows(rows)
+        own = int(((table[:, 0] == rank).sum()).item()) if table.shape[0] else 0
+        assert own == rows.shape[0], "gather lost rows of rank %d: %d != %d" % (rank, own, rows.shape[0])
+        stat["calls"] += 1
+        stat["rows"] += int(table.shape[0])
+        return int(table.shape[0])
+    return gather
 
 
 def box_iou_pairs(a, b):
@@ -102,6 +132,22 @@ class Stream:
             _, self.d_pre = self.model(imgs=self.frames[0], mode="backbone")              # reference frame: once, untimed
         self.lbs = label_map_s8(self.box, H, W, dev)
         self.results = torch.zeros((4096, 8), device=dev)
+        self.last_rows = torch.zeros((0, 8), device=dev)
+        self.seed = seed
+        if task == "mot":     # evaluate_omni loop (mot_evaluator.py:991-1045) with the native QuasiDense association
+            from unicorn_amd.tracker import OmniMOTFrame, QuasiDenseEmbedTracker
+            # synthetic weights give obj * cls ~ 1e-4: the score thresholds are set from the score distribution of one frame so that
+            # ~200 candidates reach the NMS and the association (documented in DESIGN.md); tracker thresholds follow
+            kw = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+                      memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+                      match_metric="bisoftmax")
+            with torch.no_grad():
+                o, _ = self.model(self.frames[1])
+                o = o[0] if self.cfg.mask else o
+                sc = (o[0, :, 4] * o[0, :, 5:].max(1)[0]).sort(descending=True)[0]
+            self.score_thr = float((sc[199] + sc[200]) / 2)
+            self.omni = OmniMOTFrame(self.model, QuasiDenseEmbedTracker(**kw), (H, W), num_classes=self.cfg.num_classes,
+                                     confthre=self.score_thr, nmsthre=0.7, embed_score_thr=self.score_thr)
         if task == "vos":
             from unicorn_amd.tracker import UnicornVOSTrack
             self.trk = UnicornVOSTrack(self.model, input_size=(H, W), d_rate=self.cfg.d_rate)
@@ -136,41 +182,53 @@ class Stream:
             if self.task == "sot":
                 r = self.sot_batch(self.batches[i % len(self.batches)])
                 out = r["head"][0] if self.cfg.mask else r["head"]
-                best = torch.argmax(out[:, :, 4] * out[:, :, 5], 1)       # result row stand-in (NMS top-1 stays on device, no sync)
-                self.results[i % 4096, :6] = out[0, best[0], :6]
-            elif self.task == "mot":      # evaluate_omni-style step (mot_evaluator.py:991-1034)
-                from unicorn_amd.ops import sample_embeddings
+                best = torch.argmax(out[:, :, 4] * out[:, :, 5], 1)       # result rows (top-1 per frame stays on the device, no sync)
+                B = out.shape[0]
+                rows = torch.zeros((B, 8), device=self.dev)
+                rows[:, 1] = i * B + torch.arange(B, device=self.dev)
+                rows[:, 3:7] = out[torch.arange(B, device=self.dev), best, :4]
+                rows[:, 7] = out[torch.arange(B, device=self.dev), best, 4]
+                self.last_rows = rows
+                self.results[i % 4096] = rows[0]
+            elif self.task == "mot":      # the evaluate_omni loop body over NB consecutive frames (unicorn_amd/tracker/omni.py)
                 img = self.batches[i % len(self.batches)]
-                out, d_cur = m(img)
-                out = out[0] if self.cfg.mask else out
-                f_pre, f_cur = m(seq_dict0=self.d_pre, seq_dict1=d_cur, mode="interaction")
-                e_cur = m(feat=f_cur, mode="upsample")
-                for bi in range(img.shape[0]):
-                    sc = out[bi, :, 4] * out[bi, :, 5:].max(1)[0]
-                    top = torch.topk(sc, 64)[1]
-                    b = out[bi, top, :4]
-                    boxes = torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1)
-                    emb = sample_embeddings(e_cur[bi:bi + 1], boxes)
-                    self.results[i % 4096, :4] = boxes[0]
-                    self.results[i % 4096, 4] = emb.sum()
+                res = self.omni.run_batch(img, (self.H, self.W))
+                rows = []
+                for bi, (bb, ids) in enumerate(res):
+                    if bb is not None:
+                        for k in range(bb.shape[0]):
+                            rows.append([0.0, float(i * img.shape[0] + bi), float(ids[k])] + [float(v) for v in bb[k, :5]])
+                self.last_rows = torch.tensor(rows, dtype=torch.float32).reshape(-1, 8).to(self.dev)
             else:                         # VOS: K = 3 objects, head per object, CondInst masks + postprocess (unicorn_vos.py:71-200)
                 res, _ = self.trk.step(self.frames[1 + i % (len(self.frames) - 1)])
                 d = res["1"][0]
                 if d is not None:
                     self.results[i % 4096, :7] = d
+                    self.last_rows = self.results[i % 4096:i % 4096 + 1].clone()
 
 
-def timed(streams, steps, warmup, barrier):
+def timed(streams, steps, warmup, barrier, gather=None, gather_every=1):
+    """W warm-up steps, barrier + sync, exactly K timed steps, barrier + sync.  `gather` (N > 1): the in-run RCCL gather of the
+    result rows every `gather_every` steps (external/lib/test/evaluation/running.py collects per sequence; here per step).
+    Returns (wall seconds between the barriers, this rank's own busy seconds, gathered row count)."""
+    import torch
     for i in range(warmup):
         for s in streams:
             s.step(i)
+        if gather is not None and (i + 1) % gather_every == 0:
+            gather(streams)
     barrier()
     t0 = time.perf_counter()
+    nrows = 0
     for i in range(steps):
         for s in streams:
             s.step(warmup + i)
+        if gather is not None and (i + 1) % gather_every == 0:
+            nrows += gather(streams)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     barrier()
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, own, nrows
 
 
 def main():
@@ -191,11 +249,29 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     if args.launch_check:
-        n = torch.ones(1, device="cuda:%d" % local_rank if torch.cuda.is_available() else "cpu")
+        ldev = "cuda:%d" % local_rank if torch.cuda.is_available() else "cpu"
+        n = torch.ones(1, device=ldev)
+        tasks, grows, nstr = [rank_task(args.task, args.model, 0, 1)[0]], 0, 0
         if dist is not None:
             dist.all_reduce(n)
+            # the multi-rank plumbing of the timed run with synthetic rows: task per rank, ragged row gather, byte-string gather
+            from unicorn_amd.parallel import gather_byte_strings
+            t_, _ = rank_task(args.task, args.model, rank, world)
+            code = torch.tensor([1.0 if t_ == "mot" else 0.0], device=ldev)
+            codes = [torch.zeros_like(code) for _ in range(world)]
+            dist.all_gather(codes, code)
+            tasks = [("mot" if float(c_) > 0.5 else ("sot" if args.task == "mix" else args.task)) for c_ in codes]
+
+            class _S:
+                last_rows = torch.zeros((3 + rank, 8), device=ldev)          # ragged: MOT ranks return a varying number of rows
+            st_ = {"calls": 0, "rows": 0}
+            grows = make_gather(rank, st_)([_S])
+            strs = gather_byte_strings([bytes([48 + rank]) * (5 + rank)] * (1 + rank % 2))
+            nstr = sum(len(x) for x in strs)
+            assert strs[rank] == [bytes([48 + rank]) * (5 + rank)] * (1 + rank % 2)
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": int(n.item()), "backend": "none" if dist is None else dist.get_backend()}))
+            print(json.dumps({"launch_check": True, "n_gpus": int(n.item()), "backend": "none" if dist is None else dist.get_backend(),
+                              "tasks": tasks, "gathered_rows": grows, "gathered_strings": nstr}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -214,19 +290,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    main_s = Stream(args.model, args.precision, args.task, H, W, NB, dev, seed=1 + rank, corr_prec=args.corr_precision)
-    dt = timed([main_s], args.steps, args.warmup, barrier)
+    # BASELINE.json configs[4]: "8 independent 800x1280 streams (MOT+SOT mix), one stream per GPU, RCCL gather": the first half of the
+    # ranks run the MOT loop (evaluate_omni on the MOT17-style model, num_classes = 1), the second half the SOT step
+    task, model_name = rank_task(args.task, args.model, rank, world)
+    main_s = Stream(model_name, args.precision, task, H, W, NB, dev, seed=1 + rank, corr_prec=args.corr_precision)
+    gather, gstat = None, {"calls": 0, "rows": 0}
+    if dist is not None:
+        from unicorn_amd.parallel import gather_byte_strings
+        gather = make_gather(rank, gstat)
+    dt, own_dt, _ = timed([main_s], args.steps, args.warmup, barrier, gather, max(1, args.gather_every))
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # result gather (fixed-stride rows over RCCL), outside the timed region like the reference's end-of-eval gather
-        from unicorn_amd.parallel import gather_result_rows
-        rows = main_s.results[:args.steps].clone()
-        rows[:, 0] = rank
-        rows[:, 1] = torch.arange(rows.shape[0], device=dev)
-        table = gather_result_rows(rows)
-        assert table.shape[0] == world * rows.shape[0]
+        # per-rank rate (own busy time between the barriers) and the task each rank ran
+        mine = torch.tensor([args.steps * main_s.frames_per_step() / own_dt, 1.0 if task == "mot" else 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r_, "task": "mot" if float(v[1]) > 0.5 else ("sot" if args.task in ("mix", "sot") else args.task), "fps": round(float(v[0]), 2)}
+                    for r_, v in enumerate(allr)]
+        # variable-length gather (mask RLE strings, unicorn_amd/parallel.py:gather_byte_strings): every rank encodes the box of its last
+        # result row as a mask with the device RLE kernel; rank 0 decodes every string and checks the round trip
+        from unicorn_amd.ops import rle_encode
+        hm, wm = 135, 240
+        rr = main_s.last_rows[:4] if main_s.last_rows.shape[0] else torch.zeros((1, 8), device=dev)
+        mk = torch.zeros((rr.shape[0], hm, wm), device=dev, dtype=torch.uint8)
+        bx = (rr[:, 3:7] / 8.0).clamp(min=0).long().cpu().tolist()
+        for k_, (x1, y1, x2, y2) in enumerate(bx):
+            mk[k_, min(y1, hm - 1):min(max(y2, y1 + 1), hm), min(x1, wm - 1):min(max(x2, x1 + 1), wm)] = 1
+        strs = rle_encode(mk)
+        allstr = gather_byte_strings(strs)
+        assert len(allstr) == world and len(allstr[rank]) == len(strs) and allstr[rank] == strs
+        if rank == 0:
+            from unicorn_amd.utils.masks import rle_string_to_mask
+            nstr = 0
+            for r_ in range(world):
+                for b_ in allstr[r_]:
+                    rle_string_to_mask(b_, hm, wm)          # raises unless the runs cover the hm x wm mask exactly
+                    nstr += 1
+            gstat["rle_strings"] = nstr
+            assert (torch.as_tensor(rle_string_to_mask(strs[0], hm, wm)) == mk[0].cpu()).all(), "RLE round trip failed"
     fps = world * args.steps * main_s.frames_per_step() / dt
 
     # ---------------- roofline leg: per-kernel-class HIP-event timing on the launch stream (rank 0) ----------------
@@ -275,7 +379,7 @@ def main():
                         "launches": c_["launches"]}
         extra["gemm_ms_per_frame"] = round(g["ms"], 4)
         extra["misc_ms_per_frame"] = round(cls["misc"]["ms"], 4)
-        if args.task == "sot":   # correlation kernel alone (torch events on the current stream == launch stream)
+        if task == "sot":   # correlation kernel alone (torch events on the current stream == launch stream)
             from unicorn_amd.ops import corr_softmax_pv
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             with torch.no_grad():
@@ -291,9 +395,10 @@ def main():
             n = a.shape[1]
             # precision 1 / 2 issue 6 / 3 MFMA terms per fp32-equivalent product: effective peak = 2500 / 6 or 2500 / 3 TFLOP/s
             extra["corr_fp32"] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * n * n * 128 / (ms * 1e-3) / 1e12, 2),
-                                  "peak_effective": [157.3, round(2500.0 / 6, 1), round(2500.0 / 3, 1)][args.corr_precision],
+                                  "peak_effective": [157.3, round(2500.0 / 6, 1), round(2500.0 / 3, 1), 2500.0][args.corr_precision],
                                   "mode": ["fp32 MFMA", "bf16x3 split (6 exact partial products, fp32 accumulate)",
-                                           "f16x2 split (3 partial products, fp32 accumulate)"][args.corr_precision]}
+                                           "f16x2 split (3 partial products, fp32 accumulate)",
+                                           "fp16 single pass (the reference driver's arithmetic class, not a parity mode)"][args.corr_precision]}
 
     # ---------------- CPU baseline (the oracle = port of the reference, host cores, bounded sample) + in-run parity ----------------
     cpu, parity = None, None
@@ -308,13 +413,13 @@ def main():
             cdt = 0.0
             for i in range(args.cpu_frames):
                 t1 = time.perf_counter()
-                if args.task == "mot":
+                if task == "mot":
                     o_out, _, _ = uo.mot_whole(P, cfg, cf[1 + i])
                     o = None
                 else:
                     o = uo.sot_step(P, cfg, st, cf[1 + i])
                 cdt += time.perf_counter() - t1
-                if args.task == "sot":     # parity of the TIMED configuration (same model object, same precision, same frames)
+                if task == "sot":     # parity of the TIMED configuration (same model object, same precision, same frames)
                     r = main_s.sot_batch(main_s.frames[1 + i])
                     ho = o["head"][0] if cfg.mask else o["head"]
                     hh = (r["head"][0] if cfg.mask else r["head"]).cpu()
@@ -327,7 +432,7 @@ def main():
         torch.set_num_threads(1)           # the remaining legs are GPU work: no OpenMP team next to the HIP dispatch thread
         cpu = {"value": round(args.cpu_frames / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "%d frames of the same %s %s step at %dx%d, fp32, torch CPU (oracle/unicorn_oracle.py)"
-                         % (args.cpu_frames, args.model, args.task, H, W)}
+                         % (args.cpu_frames, args.model, task, H, W)}
         if ious:
             iou = torch.cat(ious)
             parity = {"vs": "CPU oracle (fp32), %d frames of the timed stream, top-500 anchors by oracle score" % args.cpu_frames,
@@ -341,7 +446,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         def quick(model_name, precision, task, nb, steps=4, warmup=1, P=None, keep=False):
             s = Stream(model_name, precision, task, H, W, nb, dev, seed=1, corr_prec=args.corr_precision, P=P)
-            d = timed([s], steps, warmup, barrier)
+            d = timed([s], steps, warmup, barrier)[0]
             f = steps * s.frames_per_step() / d
             r = {"fps": round(f, 2), "ms_per_frame": round(1e3 / f, 4), "frames_per_step": s.frames_per_step(), "precision": precision}
             if not keep:      # one extra context (weights + workspace) alive at a time
@@ -354,30 +459,91 @@ def main():
             if prec == args.precision:
                 modes[prec] = {"fps": round(fps, 2), "ms_per_frame": round(1e3 / fps, 4), "frames_per_step": main_s.frames_per_step(), "precision": prec}
             else:
-                _, modes[prec] = quick(args.model, prec, args.task, NB, P=Pm)
+                _, modes[prec] = quick(model_name, prec, task, NB, P=Pm)
         modes["bf16"]["parity_note"] = "bf16 operands miss the box-IoU bar with synthetic weights (min ~0.56, profiles/r02_precision_budget.json)"
         # single-frame latency of the headline mode: one frame per step, synchronised every frame (the reference's own call pattern)
         with torch.no_grad():
             for _ in range(2):
-                main_s.sot_batch(main_s.frames[1]) if args.task == "sot" else main_s.step(0)
+                main_s.sot_batch(main_s.frames[1]) if task == "sot" else main_s.step(0)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             nrep = 10
             for i in range(nrep):
-                if args.task == "sot":
+                if task == "sot":
                     main_s.sot_batch(main_s.frames[1 + i % 4])
                 else:
                     main_s.step(i)
                 torch.cuda.synchronize()
             lat = (time.perf_counter() - t1) / nrep
-        if args.task == "sot":
+        if task == "sot":
             configs["single_frame_latency"] = {"ms": round(1e3 * lat, 3), "fps": round(1.0 / lat, 2), "frames_per_step": 1, "precision": args.precision,
                                                "note": "one (1,3,%d,%d) frame per call, host-synchronised per frame" % (H, W)}
         torch.cuda.empty_cache()
         # BASELINE.json configs[1..3]
         _, configs["tiny_sot"] = quick("unicorn_track_tiny", args.precision, "sot", NB)
         _, configs["tiny_sot_bf16"] = quick("unicorn_track_tiny", "bf16", "sot", NB)
-        _, configs["large_mot_challenge_step"] = quick("unicorn_track_large_mot_challenge", args.precision, "mot", NB)
+        ms_, configs["large_mot_challenge_step"] = quick("unicorn_track_large_mot_challenge", args.precision, "mot", NB, keep=True)
+        configs["large_mot_challenge_step"]["note"] = ("evaluate_omni loop body over %d consecutive frames: whole -> uni_postprocess (~200 candidates) -> interaction -> "
+                                                       "upsample -> instance embeddings -> native QuasiDense match" % NB)
+        # ---- tracker-level numbers (the reference drivers' own call pattern: one frame per call, host-synchronised), per-stage GPU ms
+        from unicorn_amd.tracker import OmniMOTSFrame, QuasiDenseEmbedTracker, UnicornSOTTrack
+        from unicorn_amd.utils.timing import StageTimer
+        g_ = torch.Generator().manual_seed(3)
+        raw = [torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, generator=g_).pin_memory() for _ in range(4)]
+
+        def staged(run, timer, n=12, warm=2):
+            for i in range(warm):
+                run(i)
+            torch.cuda.synchronize()
+            timer.summary()
+            t1_ = time.perf_counter()
+            for i in range(n):
+                timer.start()
+                run(warm + i)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t1_) / n
+            gpu_ms, host_ms = timer.summary(per=n)
+            return {"ms_per_frame": round(1e3 * wall, 3), "fps": round(1.0 / wall, 2),
+                    "stages_gpu_ms": {k: round(v, 3) for k, v in gpu_ms.items()}, "stages_host_ms": {k: round(v, 3) for k, v in host_ms.items()}}
+
+        with torch.no_grad():
+            if task == "sot" and not main_s.cfg.mask:      # (a) UnicornSOTTrack.track on raw 1080p uint8 RGB frames (pinned host memory)
+                o_ = main_s.sot_batch(main_s.frames[1])["head"]
+                sc_ = (o_[0, :, 4] * o_[0, :, 5]).sort(descending=True)[0]
+                trk = UnicornSOTTrack(main_s.model, input_size=(H, W))
+                trk.confthre = float((sc_[199] + sc_[200]) / 2)      # synthetic scores ~1e-4: ~200 candidates reach the NMS
+                trk.initialize(raw[0], {"init_bbox": [480.0, 270.0, 480.0, 540.0]})
+                trk.t = StageTimer()
+                configs["sot_track_raw_1080p"] = staged(lambda i: trk.track(raw[1 + i % 3]), trk.t)
+                configs["sot_track_raw_1080p"]["note"] = ("UnicornSOTTrack.track per frame: pinned uint8 1080p -> H2D -> uni_letterbox -> backbone+FPN -> interaction -> "
+                                                          "2 x upsample -> correlation -> head -> uni_postprocess (conf thr set for ~200 candidates) -> box")
+            # (b) evaluate_omni loop, one frame per call
+            ms_.omni.t = StageTimer()
+            ms_.omni.pre_dict, ms_.omni.frame_id = None, 0
+            configs["mot_omni_loop"] = staged(lambda i: ms_.omni.run(ms_.frames[1 + i % 4], (1080, 1920)), ms_.omni.t)
+            configs["mot_omni_loop"]["note"] = "mot_evaluator.py:991-1045 per frame on unicorn_track_large_mot_challenge, ~200 NMS candidates, native association"
+        del ms_
+        torch.cuda.empty_cache()
+        with torch.no_grad():      # (c) MOTS loop (mot_evaluator.py:770-890): CondInst masks, overlap-free merge, device RLE
+            mm_ = Stream("unicorn_track_large_mot_challenge_mask", args.precision, "mot", H, W, 1, dev, seed=1, corr_prec=args.corr_precision)
+            o_, _ = mm_.model(mm_.frames[1])
+            sc_ = (o_[0][0, :, 4] * o_[0][0, :, 5]).sort(descending=True)[0]
+            thr_ = float((sc_[63] + sc_[64]) / 2)
+            kw_ = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1, memo_momentum=0.8,
+                       nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+            mots = OmniMOTSFrame(mm_.model, QuasiDenseEmbedTracker(**kw_), (H, W), num_classes=1, confthre=thr_, nmsthre=0.7, embed_score_thr=thr_,
+                                 mask_thres=0.3, d_rate=mm_.cfg.d_rate, timer=StageTimer())
+            nrle = [0]
+
+            def run_mots(i):
+                r_ = mots.run(mm_.frames[1 + i % 4], (1080, 1920))
+                nrle[0] = len(r_[1])
+            configs["mots_loop"] = staged(run_mots, mots.t, n=8)
+            configs["mots_loop"]["rle_strings_last_frame"] = nrle[0]
+            configs["mots_loop"]["note"] = ("MOTS loop per frame on unicorn_track_large_mot_challenge_mask: postprocess_inst (64 candidates) + CondInst masks -> "
+                                            "uni_mask_resize > thr at 1080p -> association -> uni_mots_overlap_free -> uni_rle_encode strings")
+        del mm_, mots
+        torch.cuda.empty_cache()
         vs, configs["large_vos_k3"] = quick("unicorn_track_large_mask", args.precision, "vos", 1, steps=6, warmup=2, keep=True)
         configs["large_vos_k3"]["note"] = "3 objects per frame: one backbone, per object correlation + head + CondInst masks + postprocess (UnicornVOSTrack.step)"
         if not args.no_cpu_baseline:      # mask parity of the VOS config on one frame (oracle loop over the 3 objects)
@@ -416,7 +582,9 @@ def main():
                        "model": args.model, "task": args.task, "precision": args.precision, "frames_per_step": nf, "streams": world,
                        "weights": "synthetic (oracle/synth.py)",
                        "corr_dtype": ["f32", "f32-equivalent (bf16x3 split operands, fp32 accumulate)",
-                                      "f32-equivalent (f16x2 split operands, fp32 accumulate)"][args.corr_precision], "accum": "f32"},
+                                      "f32-equivalent (f16x2 split operands, fp32 accumulate)",
+                                      "f16 (single pass, reference driver class)"][args.corr_precision], "accum": "f32",
+                       "rank_tasks": per_rank, "gather": gstat if world > 1 else None},
             "parity": parity, "roofline": roof, "cpu_baseline": cpu, "modes": modes, "configs": configs, "kernels": extra,
         }
         print(json.dumps(line))

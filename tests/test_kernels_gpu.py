@@ -893,7 +893,8 @@ def test_mlp_fused(L, C_, M, with_outb):
     out = torch.full((M + pad, C_), 777.0, device="cuda")
     out[:M] = res.cuda()
     outb = torch.zeros((M + pad, C_), device="cuda", dtype=torch.int32) if with_outb else None
-    L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1.cuda()), L.ptr((gamma * b2).cuda()), ws1, ws2, L.ptr(out), C_,
+    b1d, b2d = b1.cuda(), (gamma * b2).cuda()
+    L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1d), L.ptr(b2d), ws1, ws2, L.ptr(out), C_,
                                   L.ptr(out), C_, L.ptr(outb), C_, M, C_, 0, L.stream_ptr()), "mlp_fused")
     torch.cuda.synchronize()
     got = out[:M].cpu().double()
@@ -922,15 +923,16 @@ def test_mlp_fused_matches_unfused_pair(L):
     A = cast_h2(L, x.cuda())
     blob, ws1, ws2 = mlp_pack(L, w1, w2, gamma)
     fused = res.clone()
-    L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1.cuda()), L.ptr((gamma * b2).cuda()), ws1, ws2, L.ptr(fused), C_,
+    b1d, b2d = b1.cuda(), (gamma * b2).cuda()
+    L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1d), L.ptr(b2d), ws1, ws2, L.ptr(fused), C_,
                                   L.ptr(fused), C_, None, 0, M, C_, 0, L.stream_ptr()), "mlp_fused")
     W1p, s1 = pack_weight_h2(L, w1.reshape(4 * C_, C_, 1, 1))
     W2p, s2 = pack_weight_h2(L, (gamma[:, None] * w2).reshape(C_, 4 * C_, 1, 1))
     hid = torch.zeros((M, 4 * C_), device="cuda", dtype=torch.int32)
-    L.check(L.lib().uni_gemm_h2(L.ptr(A), C_, L.ptr(W1p), s1, M, 4 * C_, M, 1, C_, 1, 1, 1, 0, L.ptr(b1.cuda()), 2, None, 0, None, 0,
+    L.check(L.lib().uni_gemm_h2(L.ptr(A), C_, L.ptr(W1p), s1, M, 4 * C_, M, 1, C_, 1, 1, 1, 0, L.ptr(b1d), 2, None, 0, None, 0,
                                 L.ptr(hid), 4 * C_, None, 0, 0, L.stream_ptr()), "pw1")
     two = torch.zeros((M, C_), device="cuda")
-    L.check(L.lib().uni_gemm_h2(L.ptr(hid), 4 * C_, L.ptr(W2p), s2, M, C_, M, 1, 4 * C_, 1, 1, 1, 0, L.ptr((gamma * b2).cuda()), 0, L.ptr(res), C_,
+    L.check(L.lib().uni_gemm_h2(L.ptr(hid), 4 * C_, L.ptr(W2p), s2, M, C_, M, 1, 4 * C_, 1, 1, 1, 0, L.ptr(b2d), 0, L.ptr(res), C_,
                                 L.ptr(two), C_, None, 0, None, 0, 0, L.stream_ptr()), "pw2")
     torch.cuda.synchronize()
     assert (fused - two).abs().max().item() < 3e-6 * max(1.0, two.abs().max().item())

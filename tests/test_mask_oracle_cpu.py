@@ -63,3 +63,20 @@ def test_overlap_free():
     o = mo.overlap_free(m)
     assert o[0].tolist() == [[1, 1, 0, 0], [0, 0, 0, 0]] and o[1].tolist() == [[0, 0, 1, 0], [0, 0, 0, 0]]
     assert o[2].tolist() == [[0, 0, 0, 1], [1, 1, 1, 1]] and (o.sum(0) <= 1).all()
+
+
+def test_product_rle_reader_inverts_the_oracle_encoder():
+    """unicorn_amd.utils.masks.rle_string_to_mask (host-side reader of gathered MOTS strings) is the inverse of the pycocotools string
+    format as restated in oracle/mask_oracle.py (rleToString of the column-major runs)."""
+    import numpy as np
+    from unicorn_amd.utils.masks import rle_string_to_mask
+    import mask_oracle as mo
+    rng = np.random.RandomState(0)
+    for h, w in [(7, 5), (135, 240), (64, 1)]:
+        m = (rng.rand(h, w) > 0.6).astype(np.uint8)
+        m[: h // 3] = 0
+        s = mo.mask_to_rle_string(m)
+        assert np.array_equal(rle_string_to_mask(s, h, w), m)
+    import pytest
+    with pytest.raises(ValueError):
+        rle_string_to_mask(mo.mask_to_rle_string(np.ones((4, 4), np.uint8)), 5, 4)

@@ -593,3 +593,61 @@ def test_layernorm_folded_into_pwconv1_optional_path():
                         "test_tiny_320_vs_reference_golden and unicorn_track_tiny_mask and not fp32"], env=env, capture_output=True, text=True,
                        cwd=ROOT, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def test_omni_mot_frame_batched_equals_per_frame_and_oracle():
+    """unicorn_amd.tracker.OmniMOTFrame = the loop body of MOTEvaluator.evaluate_omni (mot_evaluator.py:991-1045).  Three frames of the
+    tiny model: (a) one frame per call vs all frames in ONE time-batched call give the same boxes and ids, (b) the ids / boxes are
+    the oracle's (uo.mot_whole -> uo.postprocess -> interaction / upsample -> sample_instance_embeddings -> assoc_oracle.qd_match)."""
+    import copy
+    import assoc_oracle as ao
+    from unicorn_amd.tracker import OmniMOTFrame, QuasiDenseEmbedTracker
+    exp, H, W = "unicorn_track_tiny", 320, 320
+    m, cfg, P = build(exp, "f16x2")
+    frames, _ = synth.synth_clip(H, W, 4, seed=7)
+    kw = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+              memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+              match_metric="bisoftmax")
+    with torch.no_grad():
+        out_o, _, _ = uo.mot_whole(P, cfg, frames[1])
+    sc = (out_o[0, :, 4] * out_o[0, :, 5:].max(1)[0]).sort(descending=True)[0]
+    thr = float((sc[59] + sc[60]) / 2)
+    info = (480, 480)                                                 # original image: scale = 320 / 480
+    one = OmniMOTFrame(m, QuasiDenseEmbedTracker(**kw), (H, W), num_classes=cfg.num_classes, confthre=thr, nmsthre=0.7, embed_score_thr=thr)
+    bat = OmniMOTFrame(m, QuasiDenseEmbedTracker(**kw), (H, W), num_classes=cfg.num_classes, confthre=thr, nmsthre=0.7, embed_score_thr=thr)
+    with torch.no_grad():
+        r1 = [one.run(frames[f].cuda(), info) for f in (1, 2, 3)]
+        rb = bat.run_batch(torch.cat([frames[f] for f in (1, 2, 3)], 0).cuda(), info)
+    for (b1, i1), (b2, i2) in zip(r1, rb):
+        assert torch.equal(torch.as_tensor(i1), torch.as_tensor(i2))
+        assert (torch.as_tensor(b1) - torch.as_tensor(b2)).abs().max() < 1e-3
+    # oracle loop
+    st, pre = ao.QDState(**kw), None
+    scale = min(H / 480.0, W / 480.0)
+    for k, f in enumerate((1, 2, 3)):
+        with torch.no_grad():
+            o, d, _ = uo.mot_whole(P, cfg, frames[f])
+            det = uo.postprocess(o.clone(), cfg.num_classes, thr, 0.7)[0]
+            if pre is None:
+                pre = copy.deepcopy(d)
+            _, fo = uo.forward_interaction(P, pre, d)
+            e = uo.forward_upsample(P, fo)
+            pre = copy.deepcopy(d)
+        bb, s_ = det[:, :4], det[:, 4:5] * det[:, 5:6]
+        keep = s_[:, 0] > thr
+        bb, s_ = bb[keep], s_[keep]
+        emb = uo.sample_instance_embeddings(e, bb)
+        tin = torch.cat((bb / scale, s_), 1)
+        b_o, _, ids_o, _ = ao.qd_match(st, tin, torch.ones((bb.shape[0],)), emb, k + 1)
+        ids_o = torch.as_tensor(ids_o).long()
+        v = ids_o > -1
+        b_h, i_h = r1[k]
+        # scores of neighbouring detections can swap rows between the two paths: compare as id -> box maps
+        mo_ = {int(i): torch.as_tensor(b_o)[v][j] for j, i in enumerate(ids_o[v].tolist())}
+        mh_ = {int(i): torch.as_tensor(b_h)[j] for j, i in enumerate(torch.as_tensor(i_h).tolist())}
+        assert len(mo_) == len(mh_) and len(mo_) > 10
+        hit = 0
+        for bo in mo_.values():
+            d_ = torch.stack([(bo[:4] - bh[:4]).abs().max() for bh in mh_.values()])
+            hit += int(d_.min() < 0.05)
+        assert hit == len(mo_), (hit, len(mo_))

@@ -216,6 +216,14 @@ static PBlock pack_block(uni_ctx* c, const std::string& p, int C) {
     }
     const float* gamma = host_param(c, p + "gamma", C);   // layer scale folded into pwconv2 (convnext.py:50-51)
     b.pw2 = pack_conv(c, p + "pwconv2.weight", p + "pwconv2.bias", C, 4 * C, 1, 1, gamma);
+    // fused pwconv1 -> GELU -> pwconv2 -> + residual (mlp_fused.hip) for the narrow blocks of the f16x2 mode; UNI_NO_MLP_FUSED = A/B switch
+    static const bool mlp_off = getenv("UNI_NO_MLP_FUSED") != nullptr;
+    const float* w2 = host_param(c, p + "pwconv2.weight", (size_t)4 * C * C);
+    if (c->b32 == FMT_H2 && mlp_fused_supported(C) && !b.ln_folded && !mlp_off && w1 && w2 && b.pw1.bias && b.pw2.bias) {
+        std::vector<uint16_t> blob(mlp_blob_bytes(C) / 2);
+        mlp_pack_host(w1, w2, gamma, C, blob.data(), &b.mlp_ws1, &b.mlp_ws2);
+        b.mlp_blob = dev_upload<uint16_t>(c, blob.data(), blob.size());
+    }
     return b;
 }
 
@@ -554,6 +562,19 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
         const size_t before = c->recs.size();
         RUN(p_dwln(c, d, s));
         if (c->recs.size() > before) { ProfRec& r = c->recs.back(); r.M = M; r.N = C; r.K = W; }
+    }
+    // one launch, hidden activations kept in registers; below ~192 row tiles of 128 (most CUs idle) the two GEMMs with their 64 / 128-row
+    // tiles fill the chip better (measured at M = 16000: 96 vs 89 us, at M = 1000: 86 vs ~50 us)
+    if (b.mlp_blob && M >= 192 * 128) {
+        MlpArgs m;
+        m.A = t.p; m.lda = C; m.blob = b.mlp_blob; m.b1 = b.pw1.bias; m.b2 = b.pw2.bias; m.ws1 = b.mlp_ws1; m.ws2 = b.mlp_ws2;
+        m.res = x; m.ldr = C; m.out = x; m.ldo = C; m.outB = outB.p; m.ldb = C; m.M = M; m.C = C;
+        if (c->prof_on) c->prof_bytes += (double)M * C * (4.0 + 8.0 + (outB.p ? 4.0 : 0.0)) + (double)mlp_blob_bytes(C);
+        const size_t before = c->recs.size();
+        RUN(prof_run(c, PC_GEMM, 2.0 * 2.0 * M * 4.0 * C * C, s, [&] { return launch_mlp_fused(m, s); }));
+        if (c->recs.size() > before) { ProfRec& r = c->recs.back(); r.M = M; r.N = C; r.K = 4 * C; r.conv = 99; }
+        c->ws_off = mark;
+        return 0;
     }
     GemmArgs g1 = conv_args(b.pw1, t, C, M, 1, 1, 0);
     g1.rowstat = rowstat; g1.colsum = fold ? b.pw1_colsum : nullptr;

@@ -53,7 +53,7 @@ struct MlpArgs {
     float* out = nullptr; int ldo = 0;        // fp32 [M][C]
     void* outB = nullptr; int ldb = 0;        // optional f16x2 copy of the result
     int M = 0, C = 0;
-    int dbg = 0;                              // ablation switches (tools/mlp_bench.py): 1 no DMA, 2 no MFMA, 4 no stores
+    int dbg = 0;                              // ablation switches (tools/mlp_bench.py, C = 192): 1 no DMA, 2 no MFMA, 16 no GELU arithmetic, 8 (any C) every block starts its weight stream at hidden block 0
 };
 int launch_mlp_fused(const MlpArgs& a, hipStream_t s);
 bool mlp_fused_supported(int C);

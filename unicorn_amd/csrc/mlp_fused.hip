@@ -93,7 +93,14 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.blob), 0, NP * PB, 0x00020000);
     const int vo_w = lane * 16 + wave * 1024;
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
-    int p_issue = 0, src_q = 0, wr_slot = 0;         // next piece to request: its index, its position in the blob, its slot
+    // Blob order (mlp_pack_host): q = 2 i -> W1_i, q = 2 i + 1 -> W2_{i-1 mod NH}.  A block starts its tiles at hidden block h0 and consumes
+    // W1_{h0} | W1_{h0+1} W2_{h0} | ... | W1_{h0-1} W2_{h0-2} | W2_{h0-1}  (indices mod NH) = blob positions 2 h0, then 2 h0 + 2, 2 h0 + 3, ...
+    // cyclically, and 2 h0 + 1 last.  The blocks of one XCD (blockIdx & 7 fixed) spread their h0 over the stream: all CUs reading
+    // the same 24 KB at the same time would sit on the few L2 channels that hold it (4-KiB channel interleave).
+    const int h0 = (p.dbg & 8) ? 0 : (int)(((blockIdx.x >> 3) * 13u + (blockIdx.x & 7) * 5u) % NH);
+    const int q_first = 2 * h0, q_last = 2 * h0 + 1;
+    auto hb_of = [&](int step) __attribute__((always_inline)) { const int v = h0 + step; return v >= NH ? v - NH : v; };
+    int p_issue = 0, src_q = q_first, wr_slot = 0;   // next piece to request: its index, its position in the blob, its slot
     auto issue_piece_part = [&](auto II) __attribute__((always_inline)) {      // request II of the IPW of the next piece
         constexpr int i = decltype(II)::value;
         const int so = (p_issue < total && !(DBG & 1)) ? src_q * PB : 0x40000000;
@@ -102,7 +109,12 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
     };
     auto issue_piece_done = [&]() __attribute__((always_inline)) {
         ++p_issue;
-        src_q = src_q + 1 == NP ? 0 : src_q + 1;
+        if (src_q == q_last) src_q = q_first;                        // next tile
+        else {
+            int n = src_q == q_first ? src_q + 2 : src_q + 1;
+            n = n >= NP ? n - NP : n;
+            src_q = n == q_first ? q_last : n;                       // the cycle is complete: the piece held back comes last
+        }
         wr_slot = wr_slot + 1 == NSLOT ? 0 : wr_slot + 1;
     };
     auto issue_piece = [&]() __attribute__((always_inline)) {
@@ -159,55 +171,67 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
             Alo[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64 * s + 16, 0, 0));
         }
     };
-    // ---- bias + GELU + hi / lo split of the lane's 16 accumulators of a hidden block, cut into 32 sub-steps (2 quads x 4 stages x 4
-    // elements, stage-major inside a quad so the exp / rcp latencies sit between independent elements) that are dealt out one by one
-    // between the MFMAs of the neighbouring GEMM blocks.  Quad q = accumulators 4q .. 4q+3 = hidden units 8q + 4fh + e of the block =
-    // elements 4 (q & 1) .. of the k-slice q >> 1 fragment of GEMM2.  (erfc form of act_fast<ACT_GELU>, common.h.)
-    float gx[4], ge[4], gt[4], gq[4];
-    f32x4 gb;
-    f16 gh, gl;
-    auto gelu_step = [&](auto K, int q, int h, const f32x16 (&a)[CH], f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
-        constexpr int k = decltype(K)::value;        // 0 .. 15 inside the quad
-        constexpr int st = k >> 2, e = k & 3;
-        if constexpr (st == 0) {
-            if constexpr (e == 0) gb = F_LDSF(bias_rd + (32 * h + 8 * q) * 4);
-            float v = a[0][4 * q + e];
-            if (CH == 2) v += a[CH - 1][4 * q + e];
-            gx[e] = fmaf(v, ws1, gb[e]);
-            const float u = fabsf(gx[e]) * 0.84932180028801904f;
-            ge[e] = __builtin_amdgcn_exp2f(-u * u);
-            asm volatile("" : "+v"(gx[e]), "+v"(ge[e]));      // pins: the optimiser must not gather the sub-steps (or pack two elements into v_pk_* ops, slow beside MFMAs)
-        } else if constexpr (st == 1) {
-            gt[e] = __builtin_amdgcn_rcpf(fmaf(fabsf(gx[e]), 0.23164188588f, 1.f));
-            gq[e] = fmaf(fmaf(0.5307027145f, gt[e], -0.7265760135f), gt[e], 0.7107068705f);
-            asm volatile("" : "+v"(gt[e]), "+v"(gq[e]));
-        } else if constexpr (st == 2) {
-            gq[e] = fmaf(fmaf(gq[e], gt[e], -0.142248368f), gt[e], 0.127414796f);
-            ge[e] = gq[e] * gt[e] * ge[e];
-            asm volatile("" : "+v"(ge[e]));
-        } else {
-            const float y = fmaf(-fabsf(gx[e]), ge[e], fmaxf(gx[e], 0.f));
-            const float c = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
-            const f16 yh = (f16)c;
-            const f16 yl = (f16)(y - (float)yh);
-            if constexpr ((e & 1) == 0) { gh = yh; gl = yl; }
-            else {                                   // two elements per 32-bit register of the fragment
-                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
-                f16x2v ph = {gh, yh}, pl = {gl, yl};
-                unsigned uh = __builtin_bit_cast(unsigned, ph), ul = __builtin_bit_cast(unsigned, pl);
-                asm volatile("" : "+v"(uh), "+v"(ul));
-                u32x4 dh = __builtin_bit_cast(u32x4, dst[q >> 1][0]), dl = __builtin_bit_cast(u32x4, dst[q >> 1][1]);
-                dh[2 * (q & 1) + (e >> 1)] = uh;
-                dl[2 * (q & 1) + (e >> 1)] = ul;
-                dst[q >> 1][0] = __builtin_bit_cast(f16x8, dh);
-                dst[q >> 1][1] = __builtin_bit_cast(f16x8, dl);
+    // ---- bias + GELU + hi / lo split of the lane's 16 accumulators of a hidden block (erfc form of act_fast<ACT_GELU>, common.h), cut
+    // into NGS sub-steps per quad that are dealt out between the MFMAs of the neighbouring GEMM blocks.  A sub-step is ONE operation of
+    // the sequence applied to the 4 elements of the quad = 4 independent instructions (a wave alone on its SIMD stalls on every
+    // dependent VALU pair, so the dependency always crosses an MFMA); the asm pins keep the optimiser from gathering the sub-steps again
+    // or packing element pairs into v_pk_* ops (slow beside MFMAs).  Quad q = accumulators 4q .. 4q+3 = hidden units 8q + 4fh + e of
+    // the block = elements 4 (q & 1) .. of the k-slice q >> 1 fragment of GEMM2.
+    constexpr int NGS = 19;
+    float gx[2][4], ga[2][4], gt[2][4], gq[2][4];    // per quad in flight (two quads of a block are interleaved)
+    auto gelu_step = [&](auto K, auto QI, int q, int hb, const f32x16 (&a)[CH], f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value, qi = decltype(QI)::value;
+        float(&x)[4] = gx[qi];
+        float(&e_)[4] = ga[qi];
+        float(&t)[4] = gt[qi];
+        float(&w)[4] = gq[qi];
+#define G4(expr) _Pragma("unroll") for (int e = 0; e < 4; ++e) { expr; }
+#define GPIN(arr) asm volatile("" : "+v"(arr[0]), "+v"(arr[1]), "+v"(arr[2]), "+v"(arr[3]))
+        if constexpr (k == 0) {
+            const f32x4 b4 = F_LDSF(bias_rd + (32 * hb + 8 * q) * 4);
+            G4(t[e] = b4[e]);
+            G4(x[e] = a[0][4 * q + e]);
+            if (CH == 2) { G4(x[e] += a[CH - 1][4 * q + e]); }
+            if (DBG & 16) { G4(w[e] = x[e]); }
+            GPIN(x); GPIN(t);
+        } else if constexpr ((DBG & 16) != 0 && k < 18) {      // ablation: no GELU / split arithmetic
+        } else if constexpr (k == 1) { G4(x[e] = fmaf(x[e], ws1, t[e])); GPIN(x); }
+        else if constexpr (k == 2) { G4(e_[e] = fabsf(x[e]) * 0.84932180028801904f); GPIN(e_); }
+        else if constexpr (k == 3) { G4(e_[e] = -e_[e] * e_[e]); GPIN(e_); }
+        else if constexpr (k == 4) { G4(e_[e] = __builtin_amdgcn_exp2f(e_[e])); GPIN(e_); }
+        else if constexpr (k == 5) { G4(t[e] = fmaf(fabsf(x[e]), 0.23164188588f, 1.f)); GPIN(t); }
+        else if constexpr (k == 6) { G4(t[e] = __builtin_amdgcn_rcpf(t[e])); GPIN(t); }
+        else if constexpr (k == 7) { G4(w[e] = fmaf(0.5307027145f, t[e], -0.7265760135f)); GPIN(w); }
+        else if constexpr (k == 8) { G4(w[e] = fmaf(w[e], t[e], 0.7107068705f)); GPIN(w); }
+        else if constexpr (k == 9) { G4(w[e] = fmaf(w[e], t[e], -0.142248368f)); GPIN(w); }
+        else if constexpr (k == 10) { G4(w[e] = fmaf(w[e], t[e], 0.127414796f)); GPIN(w); }
+        else if constexpr (k == 11) { G4(w[e] = w[e] * t[e]); GPIN(w); }
+        else if constexpr (k == 12) { G4(w[e] = w[e] * e_[e]); GPIN(w); }
+        else if constexpr (k == 13) { G4(t[e] = fmaxf(x[e], 0.f)); GPIN(t); }
+        else if constexpr (k == 14) { G4(x[e] = fmaf(-fabsf(x[e]), w[e], t[e])); GPIN(x); }                 // x = GELU value y
+        else if constexpr (k == 15) { G4(t[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f)); GPIN(t); }
+        else if constexpr (k == 16) { G4(w[e] = (float)(f16)t[e]); GPIN(w); }                               // hi as f32 (t keeps the clamped value)
+        else if constexpr (k == 17) { G4(x[e] = x[e] - w[e]); GPIN(x); }                                    // lo
+        else {
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+            u32x4 dh = __builtin_bit_cast(u32x4, dst[q >> 1][0]), dl = __builtin_bit_cast(u32x4, dst[q >> 1][1]);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f16x2v ph = {(f16)w[2 * h2], (f16)w[2 * h2 + 1]}, pl = {(f16)x[2 * h2], (f16)x[2 * h2 + 1]};
+                dh[2 * (q & 1) + h2] = __builtin_bit_cast(unsigned, ph);
+                dl[2 * (q & 1) + h2] = __builtin_bit_cast(unsigned, pl);
             }
+            dst[q >> 1][0] = __builtin_bit_cast(f16x8, dh);
+            dst[q >> 1][1] = __builtin_bit_cast(f16x8, dl);
         }
+#undef G4
+#undef GPIN
     };
-    // sub-step `i` of the 32 that finish quads (q0, q0 + 1) of hidden block h
-    auto gelu_sub = [&](auto I, int q0, int h, const f32x16 (&a)[CH], f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
+    // sub-step `i` of the 2 * NGS that finish quads (q0, q0 + 1) of hidden block hb: the two quads alternate
+    constexpr int NSUB = 2 * NGS;
+    auto gelu_sub = [&](auto I, int q0, int hb, const f32x16 (&a)[CH], f16x8 (&dst)[2][2]) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        gelu_step(std::integral_constant<int, (i & 15)>{}, q0 + (i >> 4), h, a, dst);
+        gelu_step(std::integral_constant<int, (i >> 1)>{}, std::integral_constant<int, (i & 1)>{}, q0 + (i & 1), hb, a, dst);
     };
     // A block of MFMAs as NPAIR pair-steps: two independent accumulators alternate (m(a,t0) m(b,t0) m(a,t1) m(b,t1) m(a,t2) m(b,t2) --
     // an issue slot between two MFMAs on the SAME accumulator costs ~43 cycles, on different ones ~6), the 4 fragments of the next
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
                   [&](auto SL) __attribute__((always_inline)) {
                       constexpr int sl = decltype(SL)::value;
                       if constexpr (sl * IPW / NM != (sl + 1) * IPW / NM) issue_piece_part(std::integral_constant<int, sl * IPW / NM>{});
-                      static_for<sl * 32 / NM, (sl + 1) * 32 / NM>([&](auto I) __attribute__((always_inline)) { sub(I); });
+                      static_for<sl * NSUB / NM, (sl + 1) * NSUB / NM>([&](auto I) __attribute__((always_inline)) { sub(I); });
                   });
         issue_piece_done();
     };
@@ -274,7 +298,7 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
                   [&](auto SL) __attribute__((always_inline)) {
                       constexpr int sl = decltype(SL)::value;
                       if constexpr (sl * IPW / NM != (sl + 1) * IPW / NM) issue_piece_part(std::integral_constant<int, sl * IPW / NM>{});
-                      if constexpr (sl < nfill) static_for<sl * 32 / nfill, (sl + 1) * 32 / nfill>([&](auto I) __attribute__((always_inline)) { sub(I); });
+                      if constexpr (sl < nfill) static_for<sl * NSUB / nfill, (sl + 1) * NSUB / nfill>([&](auto I) __attribute__((always_inline)) { sub(I); });
                       extra(SL);
                   });
         issue_piece_done();
@@ -294,20 +318,20 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-        // piece order of a tile (mlp_pack_host): W1_0 | W1_1 W2_0 | W1_2 W2_1 | ... | W1_{NH-1} W2_{NH-2} | W2_{NH-1}
+        // piece order of a tile: W1_0 | W1_1 W2_0 | W1_2 W2_1 | ... | W1_{NH-1} W2_{NH-2} | W2_{NH-1}, hidden-block indices relative to h0
         // schedule: block A_h = GEMM1(h + 1) beside the second half of GELU(h); block B_h = GEMM2(h) beside the first half of GELU(h + 1)
         block_a(piece_begin(), acc1[0], nosub);
-        static_for<0, 32>([&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, 0, acc1[0], hf[0]); });
+        static_for<0, NSUB>([&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, hb_of(0), acc1[0], hf[0]); });
         constexpr auto FULL = std::integral_constant<int, 6 * NJ>{};
 #pragma unroll 1
         for (int h = 0; h < NH - 2; h += 2) {        // NH is even: pairs (h, h + 1), then the single block NH - 2 below
-            block_a(piece_begin(), acc1[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, h, acc1[0], hf[0]); });
-            block_b(piece_begin(), hf[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, h + 1, acc1[1], hf[1]); }, FULL, nosub);
-            block_a(piece_begin(), acc1[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, h + 1, acc1[1], hf[1]); });
-            block_b(piece_begin(), hf[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, h + 2, acc1[0], hf[0]); }, FULL, nosub);
+            block_a(piece_begin(), acc1[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, hb_of(h), acc1[0], hf[0]); });
+            block_b(piece_begin(), hf[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, hb_of(h + 1), acc1[1], hf[1]); }, FULL, nosub);
+            block_a(piece_begin(), acc1[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, hb_of(h + 1), acc1[1], hf[1]); });
+            block_b(piece_begin(), hf[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, hb_of(h + 2), acc1[0], hf[0]); }, FULL, nosub);
         }
-        block_a(piece_begin(), acc1[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, NH - 2, acc1[0], hf[0]); });
-        block_b(piece_begin(), hf[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, NH - 1, acc1[1], hf[1]); }, FULL, nosub);
+        block_a(piece_begin(), acc1[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, hb_of(NH - 2), acc1[0], hf[0]); });
+        block_b(piece_begin(), hf[0], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 0, hb_of(NH - 1), acc1[1], hf[1]); }, FULL, nosub);
         // the A fragments are dead: their registers take the residual rows (accumulator layout: 16 B of row fr per (j, g)), requested
         // beside the last GEMM2
         const int rows = min(BMF, p.M - m0);
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
         f32x4 rv[NJ][4];
         // last block: the second half of GELU(NH - 1) must be complete before the k-slice-1 items (second half of the slots), so its
         // sub-steps are dealt out over the first third; the residual requests follow, one per slot
-        block_b(piece_begin(), hf[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, NH - 1, acc1[1], hf[1]); },
+        block_b(piece_begin(), hf[1], [&](auto I) __attribute__((always_inline)) { gelu_sub(I, 2, hb_of(NH - 1), acc1[1], hf[1]); },
                 std::integral_constant<int, 2 * NJ>{}, [&](auto SL) __attribute__((always_inline)) {
                     constexpr int sl = decltype(SL)::value;
                     constexpr int r0 = sl * 4 * NJ / (6 * NJ), r1 = (sl + 1) * 4 * NJ / (6 * NJ);
@@ -401,13 +425,10 @@ void mlp_pack_host(const float* w1, const float* w2, const float* gamma, int C, 
                 }
     };
     const size_t pe = (size_t)PB / 2;                // uint16 per piece
-    size_t q = 0;
-    piece_w1(0, out + (q++) * pe);
-    for (int h = 0; h + 1 < NH; ++h) {
-        piece_w1(h + 1, out + (q++) * pe);
-        piece_w2(h, out + (q++) * pe);
+    for (int i = 0; i < NH; ++i) {                   // blob position 2 i: W1_i, 2 i + 1: W2_{i-1 mod NH} (the kernel's cyclic consumption order)
+        piece_w1(i, out + (size_t)(2 * i) * pe);
+        piece_w2((i + NH - 1) % NH, out + (size_t)(2 * i + 1) * pe);
     }
-    piece_w2(NH - 1, out + (q++) * pe);
 }
 
 template <int C, int CH, bool OUTB, int DBG>
@@ -432,6 +453,8 @@ static int launch_mlp_inst(const MlpArgs& a, int grid, hipStream_t s) {
             case 2: return launch_mlp_k<192, 2, false, 2>(a, grid, s);
             case 3: return launch_mlp_k<192, 2, false, 3>(a, grid, s);
             case 4: return launch_mlp_k<192, 2, false, 4>(a, grid, s);
+            case 16: return launch_mlp_k<192, 2, false, 16>(a, grid, s);
+            case 17: return launch_mlp_k<192, 2, false, 17>(a, grid, s);
             default: break;
         }
     }

@@ -7,10 +7,10 @@ Images are taken already letter-boxed as (1,3,H,W) BGR 0-255 float tensors or ra
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from ..ops import corr_softmax_pv, label_map_s8, letterbox, prior_pyramid
 from ..utils.boxes import postprocess
+from ..utils.timing import NoTimer
 
 
 class UnicornSOTTrack:
@@ -24,6 +24,7 @@ class UnicornSOTTrack:
         self.device = device
         self.state = None
         self.frame_id = 0
+        self.t = NoTimer()           # bench.py sets a StageTimer here for the per-stage numbers
 
     def _prep(self, image):
         """PreprocessorX.process (unicorn_sot.py:111-123): RGB->BGR, cv2-style 8-bit bilinear resize by r=min(H/h,W/w), pad 114."""
@@ -46,19 +47,26 @@ class UnicornSOTTrack:
     def get_det_results(self, cur):
         with torch.no_grad():
             fpn, d_cur = self.model(imgs=cur, mode="backbone")
+            self.t.mark("backbone+fpn")
             f_pre, f_cur = self.model(seq_dict0=self.out_dict_pre, seq_dict1=d_cur, mode="interaction")
             e_pre = self.model(feat=f_pre, mode="upsample")
             e_cur = self.model(feat=f_cur, mode="upsample")
+            self.t.mark("interaction+upsample")
             pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), self.lbs_pre,
                                    precision=0 if getattr(self.model, "precision", "bf16") == "fp32" else 2)
             coarse = pred.view(1, -1, self.dh, self.dw)
+            self.t.mark("correlation")
             outputs = self.model.head(fpn, prior_pyramid(coarse), mode="sot")
             outputs = outputs[0] if isinstance(outputs, tuple) else outputs
-            return postprocess(outputs, self.num_classes, self.confthre, self.nmsthre)[0]
+            self.t.mark("head")
+            det = postprocess(outputs, self.num_classes, self.confthre, self.nmsthre)[0]
+            self.t.mark("postprocess")
+            return det
 
     def track(self, image, info=None):
         self.frame_id += 1
         cur, r = self._prep(image)
+        self.t.mark("h2d+letterbox")
         output = self.get_det_results(cur)
         if output is not None:
             output[:, 0:4:2] = output[:, 0:4:2].clamp(min=0, max=self.input_size[1])
@@ -68,4 +76,5 @@ class UnicornSOTTrack:
             b[:, 2] -= b[:, 0]
             b[:, 3] -= b[:, 1]
             self.state = [int(v) for v in b[0]]
+        self.t.mark("box")
         return {"target_bbox": self.state}

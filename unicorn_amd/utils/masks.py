@@ -30,3 +30,32 @@ def mots_rle(masks, order=None):
         return masks, []
     free = mots_overlap_free(masks)
     return free, [b.decode("utf-8") for b in rle_encode(free)]
+
+
+def rle_string_to_mask(s, h, w):
+    """Inverse of the strings `mots_rle` / `rle_encode` produce (pycocotools maskApi.c rleFrString + rleDecode): compressed counts string
+    -> (h, w) uint8 numpy mask, column-major runs starting with zeros.  Host-side reader of gathered result strings."""
+    import numpy as np
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    if sum(cnts) != h * w:
+        raise ValueError("RLE string does not describe a %d x %d mask (runs sum to %d)" % (h, w, sum(cnts)))
+    v = np.zeros(h * w, dtype=np.uint8)
+    pos, val = 0, 0
+    for c in cnts:
+        v[pos:pos + c] = val
+        pos += c
+        val ^= 1
+    return v.reshape((h, w), order="F")
