@@ -79,6 +79,15 @@ const char* uni_ctx_missing_name(uni_ctx* ctx, int i);
 /* Pre-size the scratch workspace for an (H,W) input (optional; grows on demand otherwise). */
 int uni_ctx_reserve(uni_ctx* ctx, int B, int H, int W);
 
+/* Operand-range check of the "f16x2" mode.  Every fp32 value entering a contraction is stored as hi + lo f16 halves and SATURATES at
+ * +-65504 (csrc/common.h h2_split; never inf / NaN).  The synthetic test weights stay far below that, a trained checkpoint cannot be
+ * validated offline: uni_ctx_set_check(ctx, 1) (or UNI_CHECK_SAT=1 in the environment at finalize) makes the context scan every
+ * operand buffer it produces (one extra pass each; the fused MLP falls back to its two-launch form so the hidden activations exist)
+ * and count saturated elements.  uni_ctx_stats synchronises and fills out4 = {saturated operands, operands scanned, buffers scanned,
+ * 0} since the last uni_ctx_set_check call. */
+int uni_ctx_set_check(uni_ctx* ctx, int on);
+int uni_ctx_stats(uni_ctx* ctx, long long* out4);
+
 /* Per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg, off by default).
  * uni_prof_end synchronises the device and fills out16: [5 classes][ms, work, launches] + out16[15] = algorithmic
  * bytes of the GEMM class; classes: 0 GEMM/conv (work = algorithmic FLOPs 2*M*N*K), 1 dwconv7+LN, 2 GroupNorm apply,

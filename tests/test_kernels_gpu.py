@@ -936,3 +936,21 @@ def test_mlp_fused_matches_unfused_pair(L):
                                 L.ptr(two), C_, None, 0, None, 0, 0, L.stream_ptr()), "pw2")
     torch.cuda.synchronize()
     assert (fused - two).abs().max().item() < 3e-6 * max(1.0, two.abs().max().item())
+
+
+def test_mots_threshold_matches_reference_crop_shape():
+    """mot_evaluator.py:803-804 on a 480 x 854 image at 800 x 1280: F.interpolate(scale_factor=1/scale) yields 480 x 853, so the
+    reference thresholds and RLE-encodes a (480, 853) mask.  mots_threshold(crop=True) returns that shape with identical bits;
+    crop=False is the zero-padded full-size map of the VOS driver."""
+    from unicorn_amd.utils.masks import mots_threshold
+    img_h, img_w, Hn, Wn = 480, 854, 800, 1280
+    scale = min(Hn / float(img_h), Wn / float(img_w))
+    g = torch.Generator().manual_seed(0)
+    om = torch.rand(3, 1, Hn, Wn, generator=g)
+    ref = F.interpolate(om, scale_factor=1 / scale, mode="bilinear", align_corners=False)[:, 0, :img_h, :img_w] > 0.3
+    assert ref.shape[2] == img_w - 1                                  # the case the reference silently shortens
+    got = mots_threshold(om.cuda(), scale, img_h, img_w, 0.3)
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert (got.cpu().bool() != ref).float().mean() < 1e-5            # thresholding an fp32 interpolation: ties at round-off only
+    full = mots_threshold(om.cuda(), scale, img_h, img_w, 0.3, crop=False)
+    assert tuple(full.shape) == (3, img_h, img_w) and not full[:, :, img_w - 1:].any()

@@ -227,6 +227,7 @@ def _assert_bar(met, precision):
     assert met["coarse_maxabs"] < prior_tol, met
     if precision in EXACT:                                                                   # north_star: IoU >= 0.999
         assert met["box_iou_min_top500"] > 0.999, met
+        assert met["box_iou_min_all"] > 0.999, met          # every anchor, not only the top-scoring ones (VERDICT r02 weak #1d)
         if "sot_box_iou" in met:
             assert met["sot_box_iou"] > 0.999, met
         if "mask_iou_min" in met:
@@ -651,3 +652,37 @@ def test_omni_mot_frame_batched_equals_per_frame_and_oracle():
             d_ = torch.stack([(bo[:4] - bh[:4]).abs().max() for bh in mh_.values()])
             hit += int(d_.min() < 0.05)
         assert hit == len(mo_), (hit, len(mo_))
+
+
+def test_saturation_check_mode_counts_planted_outliers():
+    """The f16x2 operand format saturates at +-65504 (csrc/common.h h2_split): no inf / NaN ever reaches an MFMA, and a context in check
+    mode (uni_ctx_set_check) counts saturated operands.  (a) synthetic weights: operand buffers are scanned and nothing saturates, the
+    outputs equal the unchecked run; (b) one ConvNeXt block with pwconv1 scaled by 1e6 (GELU hidden activations far beyond the f16
+    range): the counter is raised, the outputs stay finite."""
+    name, H, W = "unicorn_track_tiny", 320, 320
+    cfg = uo.CONFIGS[name]
+    P = synth.synth_state_dict(cfg)
+    frames, _ = synth.synth_clip(H, W, 2, seed=1)
+    from unicorn_amd.models import Unicorn
+    m = Unicorn(name).cuda(0)
+    assert m.precision == "f16x2"                                  # the parity mode is the default
+    m.load_state_dict(P)
+    with torch.no_grad():
+        ref_fpn, _ = m(imgs=frames[1].cuda(), mode="backbone")
+        m.check_saturation(True)
+        fpn, _ = m(imgs=frames[1].cuda(), mode="backbone")
+    st = m.saturation_stats()
+    assert st["saturated"] == 0 and st["scanned"] > 1e6 and st["buffers"] > 50, st
+    for a, b in zip(fpn, ref_fpn):
+        assert (a - b).abs().max() < 1e-4 * b.abs().max()          # check mode only changes the launch plan (two-launch MLP)
+    P2 = {k: v.clone() for k, v in P.items()}
+    P2["backbone.backbone.stages.1.0.pwconv1.weight"] *= 1e6
+    m2 = Unicorn(name).cuda(0)
+    m2.load_state_dict(P2)
+    m2.check_saturation(True)
+    with torch.no_grad():
+        fpn2, _ = m2(imgs=frames[1].cuda(), mode="backbone")
+    st2 = m2.saturation_stats()
+    assert st2["saturated"] > 0, st2
+    assert all(torch.isfinite(t).all() for t in fpn2)
+    m2.check_saturation(False)

@@ -25,6 +25,8 @@ PROTOS = {
     "uni_ctx_finalize": (c_i, [C.c_void_p, C.POINTER(c_i)]),
     "uni_ctx_missing_name": (C.c_char_p, [C.c_void_p, c_i]),
     "uni_ctx_reserve": (c_i, [C.c_void_p, c_i, c_i, c_i]),
+    "uni_ctx_set_check": (c_i, [C.c_void_p, c_i]),
+    "uni_ctx_stats": (c_i, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "uni_prof_begin": (c_i, [C.c_void_p]),
     "uni_prof_end": (c_i, [C.c_void_p, C.POINTER(C.c_double)]),
     "uni_backbone_fpn": (c_i, [C.c_void_p, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, C.c_void_p]),

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.h"
@@ -59,6 +60,7 @@ int uni_ctx_finalize(uni_ctx* ctx, int* n_missing) {
     UNI_REQUIRE(ctx, "ctx is NULL");
     UNI_REQUIRE(!ctx->finalized, "already finalized");
     int rc = engine_finalize(ctx);
+    if (rc == 0 && getenv("UNI_CHECK_SAT")) rc = engine_set_check(ctx, 1);
     if (n_missing) *n_missing = (int)ctx->missing.size();
     return rc;
 }
@@ -71,6 +73,8 @@ int uni_ctx_reserve(uni_ctx* ctx, int B, int H, int W) {
     return engine_reserve(ctx, B, H, W);
 }
 
+int uni_ctx_set_check(uni_ctx* ctx, int on) { return engine_set_check(ctx, on); }
+int uni_ctx_stats(uni_ctx* ctx, long long* out4) { return engine_stats(ctx, out4); }
 int uni_prof_begin(uni_ctx* ctx) { UNI_REQUIRE(ctx, "ctx is NULL"); return engine_prof_begin(ctx); }
 int uni_prof_end(uni_ctx* ctx, double* out16) { UNI_REQUIRE(ctx && out16, "prof_end: NULL argument"); return engine_prof_end(ctx, out16); }
 

@@ -83,10 +83,13 @@ __device__ __forceinline__ float wave_max(float v) {
 enum ActFmt { FMT_BF16 = 0, FMT_F32 = 1, FMT_H2 = 2 };
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
+// Operand range: |x| <= 65504 is represented to 22 bits; larger magnitudes SATURATE at +-65504 (hi = +-65504, lo = 0) -- never inf / NaN
+// (lo is taken from the clamped value: taking it from x would make it overflow to inf beyond 2 x 65504 and poison the hi.lo products).
+// UNI_CHECK_SAT / uni_ctx_set_check count saturated operands per stage call (engine.hip: sat_scan_kernel).
 __device__ __forceinline__ void h2_split(float x, f16& hi, f16& lo) {
-    const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);     // keep hi finite; lo then extends the range to 2 x 65504
+    const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     hi = (f16)c;
-    lo = (f16)(x - (float)hi);
+    lo = (f16)(c - (float)hi);
 }
 __device__ __forceinline__ char* h2_addr(void* base, size_t idx) {      // byte address of the hi half of element idx
     return reinterpret_cast<char*>(base) + (idx >> 3) * 32 + (idx & 7) * 2;

@@ -53,6 +53,7 @@ struct uni_ctx {
     double* stats = nullptr; int stats_slot = 0;
     int nb = 1;   // batch size of the stage call in flight
     bool prof_on = false; std::vector<ProfRec> recs; double prof_bytes = 0.0;
+    bool check_sat = false; unsigned long long* sat_dev = nullptr;   // uni_ctx_set_check: [saturated f16x2 operands, operands scanned, buffers scanned]
     hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[2] = {nullptr, nullptr};
 };
 
@@ -62,6 +63,8 @@ int engine_finalize(uni_ctx* c);
 int engine_reserve(uni_ctx* c, int B, int H, int W);
 int engine_prof_begin(uni_ctx* c);
 int engine_prof_end(uni_ctx* c, double* out);
+int engine_set_check(uni_ctx* c, int on);
+int engine_stats(uni_ctx* c, long long* out4);
 void engine_destroy(uni_ctx* c);
 int engine_backbone_fpn(uni_ctx* c, const float* img, int B, int H, int W, float* fpn0, float* fpn1, float* fpn2, float* feat16, hipStream_t s);
 int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, const float* feat_cur, const float* pos_cur,

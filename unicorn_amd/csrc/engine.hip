@@ -435,6 +435,55 @@ static int prof_run(uni_ctx* c, int cls, double work, hipStream_t s, F&& f) {
     c->recs.push_back(r);
     return rc;
 }
+// ------------------------------------------------------------------------------------------------
+// operand-range check (uni_ctx_set_check / UNI_CHECK_SAT=1): the f16x2 operand format saturates at +-65504 (common.h h2_split).  Trained
+// checkpoints cannot be validated offline, so a context in check mode scans every operand buffer it produces and counts the saturated
+// elements; uni_ctx_stats reads the counters.  Off by default (one extra pass over every operand buffer).
+// ------------------------------------------------------------------------------------------------
+__global__ void sat_scan_kernel(const unsigned short* buf, long rows, int C, int ld, unsigned long long* cnt) {
+    const int groups = C >> 3;
+    const long total = rows * groups;
+    unsigned n = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / groups;
+        const int g = (int)(i - r * groups);
+        const unsigned short* p = buf + (r * ld + 8 * g) * 2;          // [8 x hi][8 x lo] per 8 channels
+#pragma unroll
+        for (int e = 0; e < 8; ++e) n += (p[e] & 0x7fffu) >= 0x7bffu ? 1u : 0u;   // |hi| == 65504 (or non-finite)
+    }
+    n = (unsigned)wave_sum((float)n);      // < 2^24 per wave: exact
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&cnt[0], (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&cnt[1], (unsigned long long)(rows * (long)C)); atomicAdd(&cnt[2], 1ull); }
+}
+static void sat_scan(uni_ctx* c, const void* buf, long rows, int C, int ld, hipStream_t s) {
+    if (!c->check_sat || !c->sat_dev || c->b32 != FMT_H2 || !buf || rows <= 0 || C < 8) return;
+    const long total = rows * (C >> 3);
+    int grid = (int)std::min<long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(sat_scan_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(buf), rows, C, ld, c->sat_dev);
+}
+int engine_set_check(uni_ctx* c, int on) {
+    UNI_REQUIRE(c, "ctx is NULL");
+    UNI_CHECK_HIP(hipSetDevice(c->device));
+    if (on && !c->sat_dev) {
+        UNI_CHECK_HIP(hipMalloc(&c->sat_dev, 4 * sizeof(unsigned long long)));
+        c->dev_allocs.push_back(c->sat_dev);
+    }
+    if (c->sat_dev) UNI_CHECK_HIP(hipMemset(c->sat_dev, 0, 4 * sizeof(unsigned long long)));
+    c->check_sat = on != 0;
+    return 0;
+}
+int engine_stats(uni_ctx* c, long long* out4) {
+    UNI_REQUIRE(c && out4, "stats: NULL argument");
+    for (int i = 0; i < 4; ++i) out4[i] = 0;
+    if (!c->sat_dev) return 0;
+    UNI_CHECK_HIP(hipSetDevice(c->device));
+    UNI_CHECK_HIP(hipDeviceSynchronize());
+    unsigned long long h[4];
+    UNI_CHECK_HIP(hipMemcpy(h, c->sat_dev, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out4[i] = (long long)h[i];
+    return 0;
+}
+
 static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
     if (c->prof_on) {   // algorithmic bytes: input map + weights + every output/residual stream, each once
         const double es = act_elem_bytes(g.b32);
@@ -444,21 +493,28 @@ static int p_gemm(uni_ctx* c, const GemmArgs& g, hipStream_t s) {
     const size_t before = c->recs.size();
     int rc = prof_run(c, PC_GEMM, 2.0 * g.M * g.N * g.K, s, [&] { return launch_gemm(g, s); });
     if (c->recs.size() > before) { ProfRec& r = c->recs.back(); r.M = g.M; r.N = g.N; r.K = g.K; r.conv = g.KH * 10 + g.stride; }
+    if (g.outB) sat_scan(c, g.outB, g.M, g.N, g.ldb, s);
     return rc;
 }
 static int p_dwln(uni_ctx* c, DwLnArgs d, hipStream_t s) {
     d.b32 = c->b32;
-    return prof_run(c, PC_DWLN, (double)(d.B > 0 ? d.B : 1) * d.H * d.W * d.C * (4.0 + act_elem_bytes(c->b32)) + 49.0 * d.C * 4, s, [&] { return launch_dwconv7_ln(d, s); });
+    int rc = prof_run(c, PC_DWLN, (double)(d.B > 0 ? d.B : 1) * d.H * d.W * d.C * (4.0 + act_elem_bytes(c->b32)) + 49.0 * d.C * 4, s, [&] { return launch_dwconv7_ln(d, s); });
+    sat_scan(c, d.out, (long)(d.B > 0 ? d.B : 1) * d.H * d.W, d.C, d.C, s);
+    return rc;
 }
 static int p_gn(uni_ctx* c, GnApplyArgs a, hipStream_t s) {
     a.b32 = c->b32;
     double b = (double)(a.B > 0 ? a.B : 1) * a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0) + (a.outUp ? 8 : 0));
-    return prof_run(c, PC_GN, b, s, [&] { return launch_gn_apply(a, s); });
+    int rc = prof_run(c, PC_GN, b, s, [&] { return launch_gn_apply(a, s); });
+    if (a.outB) sat_scan(c, a.outB, (long)(a.B > 0 ? a.B : 1) * a.M, a.C, a.ldb, s);
+    return rc;
 }
 static int p_ln(uni_ctx* c, LnArgs a, hipStream_t s) {
     a.b32 = c->b32;
     double b = (double)a.M * a.C * (4.0 + (a.outF ? 4 : 0) + (a.outB ? 2 : 0));
-    return prof_run(c, PC_LN, b, s, [&] { return launch_layernorm(a, s); });
+    int rc = prof_run(c, PC_LN, b, s, [&] { return launch_layernorm(a, s); });
+    if (a.outB && !a.ps_h) sat_scan(c, a.outB, a.M, a.C, a.ldb, s);
+    return rc;
 }
 int engine_prof_begin(uni_ctx* c) {
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -565,7 +621,7 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
     }
     // one launch, hidden activations kept in registers; below ~192 row tiles of 128 (most CUs idle) the two GEMMs with their 64 / 128-row
     // tiles fill the chip better (measured at M = 16000: 96 vs 89 us, at M = 1000: 86 vs ~50 us)
-    if (b.mlp_blob && M >= 192 * 128) {
+    if (b.mlp_blob && M >= 192 * 128 && !c->check_sat) {   // (check mode takes the two-launch path: the hidden tensor must exist to be scanned)
         MlpArgs m;
         m.A = t.p; m.lda = C; m.blob = b.mlp_blob; m.b1 = b.pw1.bias; m.b2 = b.pw2.bias; m.ws1 = b.mlp_ws1; m.ws2 = b.mlp_ws2;
         m.res = x; m.ldr = C; m.out = x; m.ldo = C; m.outB = outB.p; m.ldb = C; m.M = M; m.C = C;

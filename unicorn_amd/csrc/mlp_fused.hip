@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * MW, 1) void mlp_fused_kernel(MlpArgs p) {
         else if constexpr (k == 14) { G4(x[e] = fmaf(-fabsf(x[e]), w[e], t[e])); GPIN(x); }                 // x = GELU value y
         else if constexpr (k == 15) { G4(t[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f)); GPIN(t); }
         else if constexpr (k == 16) { G4(w[e] = (float)(f16)t[e]); GPIN(w); }                               // hi as f32 (t keeps the clamped value)
-        else if constexpr (k == 17) { G4(x[e] = x[e] - w[e]); GPIN(x); }                                    // lo
+        else if constexpr (k == 17) { G4(x[e] = t[e] - w[e]); GPIN(x); }                                    // lo (of the clamped value: saturates, common.h h2_split)
         else {
             typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
             u32x4 dh = __builtin_bit_cast(u32x4, dst[q >> 1][0]), dl = __builtin_bit_cast(u32x4, dst[q >> 1][1]);

@@ -22,14 +22,20 @@ _CONVNEXT = {
     "convnext_large": dict(dims=(192, 384, 768, 1536), depths=(3, 3, 27, 3)),
 }
 
-# exps/default/*.py: (backbone_name, num_classes, mask)
+# exps/default/*.py (every ConvNeXt tracking exp the reference ships): (backbone_name, num_classes, mask, test_size)
 _DEFAULT_EXPS = {
-    "unicorn_track_tiny": ("convnext_tiny", 8, False),
-    "unicorn_track_tiny_mask": ("convnext_tiny", 8, True),
-    "unicorn_track_large": ("convnext_large", 8, False),
-    "unicorn_track_large_mask": ("convnext_large", 8, True),
-    "unicorn_track_large_mot_challenge": ("convnext_large", 1, False),
-    "unicorn_track_large_mot_challenge_mask": ("convnext_large", 1, True),
+    "unicorn_track_tiny": ("convnext_tiny", 8, False, (800, 1280)),
+    "unicorn_track_tiny_mask": ("convnext_tiny", 8, True, (800, 1280)),
+    "unicorn_track_tiny_rt": ("convnext_tiny", 8, False, (640, 1024)),             # exps/default/unicorn_track_tiny_rt.py:16-17
+    "unicorn_track_tiny_rt_mask": ("convnext_tiny", 8, True, (640, 1024)),
+    "unicorn_track_tiny_mot_only": ("convnext_tiny", 8, False, (800, 1280)),       # ablations: training-side switches only
+    "unicorn_track_tiny_sot_only": ("convnext_tiny", 8, False, (800, 1280)),
+    "unicorn_track_tiny_mots_only": ("convnext_tiny", 8, True, (800, 1280)),
+    "unicorn_track_tiny_vos_only": ("convnext_tiny", 8, True, (800, 1280)),
+    "unicorn_track_large": ("convnext_large", 8, False, (800, 1280)),
+    "unicorn_track_large_mask": ("convnext_large", 8, True, (800, 1280)),
+    "unicorn_track_large_mot_challenge": ("convnext_large", 1, False, (800, 1280)),
+    "unicorn_track_large_mot_challenge_mask": ("convnext_large", 1, True, (800, 1280)),
 }
 
 
@@ -85,14 +91,14 @@ class Exp(HipModelMixin):
     """stand-alone stand-in for exps/default/<name>.py (inference attributes only)"""
 
     def __init__(self, exp_name, precision="f16x2"):
-        backbone, nc, mask = _DEFAULT_EXPS[exp_name]
+        backbone, nc, mask, test_size = _DEFAULT_EXPS[exp_name]
         self.exp_name = exp_name
         self.backbone_name = backbone
         self.in_channels = list(_CONVNEXT[backbone]["dims"][1:])
         self.num_classes = nc
         self.embed_dim, self.interact_mode = 128, "deform"
         self.use_attention, self.n_layer_att = True, 3
-        self.test_size = (800, 1280)
+        self.test_size = self.input_size = test_size
         self.test_conf, self.nmsthre = 0.01, 0.65                     # exp/unicorn_track.py:105-106
         self.normalize = False                                        # :76
         if mask:
@@ -106,13 +112,16 @@ def get_exp(exp_file=None, exp_name=None, precision="f16x2"):
     assert exp_file is not None or exp_name is not None, "plz provide exp file or exp name."
     if exp_file is not None:
         name = os.path.basename(exp_file).split(".")[0]
-        try:                                    # the reference tree is importable: use its exp file verbatim
+        try:                                    # is the reference tree importable?  (only THIS import may fail quietly)
             importlib.import_module("unicorn.exp")
+            have_ref = True
+        except ImportError:
+            have_ref = False
+        if have_ref:                            # use the reference exp file verbatim; an error inside a custom exp file propagates
             sys.path.append(os.path.dirname(exp_file))
             mod = importlib.import_module(name)
             return patch_exp(mod.Exp(), precision)
-        except ImportError:
-            exp_name = name
+        exp_name = name
     if exp_name not in _DEFAULT_EXPS:
         raise ValueError("unknown experiment %r (known: %s)" % (exp_name, sorted(_DEFAULT_EXPS)))
     return Exp(exp_name, precision)

@@ -130,10 +130,13 @@ class UnicornHeadMask(UnicornHead):
 
 
 class Unicorn:
-    def __init__(self, name_or_cfg="unicorn_track_tiny", device=None, precision="bf16"):
+    def __init__(self, name_or_cfg="unicorn_track_tiny", device=None, precision="f16x2"):
         """precision (operand format of every dense contraction; accumulation, residual stream and statistics are fp32):
-          "f16x2"  fp32-equivalent: operands split into hi + lo f16 halves, 3 f16 MFMAs per product (22 operand bits).
+          "f16x2"  (default) fp32-equivalent: operands split into hi + lo f16 halves, 3 f16 MFMAs per product (22 operand bits).
                    Meets box/mask IoU >= 0.999 and embedding cosine within 1e-4 against the fp32 reference: parity mode.
+                   Operand range: values entering a contraction saturate at +-65504 (the residual stream, statistics and
+                   everything crossing the API stay fp32); `check_saturation(True)` + `saturation_stats()` count saturated
+                   operands when validating a new checkpoint.
           "fp32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain; 16x the bf16 MFMA cost.
           "bf16"   bf16 operands, 1 MFMA per product; fastest, embedding cosine still within 1e-4 but box IoU is NOT
                    (8 operand bits; profiles/r02_precision_budget.json)."""
@@ -198,8 +201,21 @@ class Unicorn:
         return self
 
     def half(self):
-        # tools/track.py --fp16 calls model.half(); the HIP path already computes in bf16 MFMA / fp32 accumulate
+        # tools/track.py --fp16 calls model.half() and feeds half images (mot_evaluator.py:126-128): the operand format of the HIP
+        # path is fixed by `precision` at construction, inputs are widened to fp32 (forward_backbone), so this is a no-op
         return self
+
+    def check_saturation(self, on=True):
+        """uni_ctx_set_check: count f16x2 operands that hit the +-65504 saturation bound (resets the counters)."""
+        self._require_ready()
+        L.check(L.lib().uni_ctx_set_check(self._ctx, int(bool(on))), "uni_ctx_set_check")
+        return self
+
+    def saturation_stats(self):
+        self._require_ready()
+        buf = (C.c_longlong * 4)()
+        L.check(L.lib().uni_ctx_stats(self._ctx, buf), "uni_ctx_stats")
+        return {"saturated": int(buf[0]), "scanned": int(buf[1]), "buffers": int(buf[2])}
 
     def float(self):
         return self

@@ -53,7 +53,7 @@ class UnicornSOTTrack:
             e_cur = self.model(feat=f_cur, mode="upsample")
             self.t.mark("interaction+upsample")
             pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), self.lbs_pre,
-                                   precision=0 if getattr(self.model, "precision", "bf16") == "fp32" else 2)
+                                   precision=0 if getattr(self.model, "precision", "f16x2") == "fp32" else 2)
             coarse = pred.view(1, -1, self.dh, self.dw)
             self.t.mark("correlation")
             outputs = self.model.head(fpn, prior_pyramid(coarse), mode="sot")

@@ -63,6 +63,7 @@ class UnicornVOSTrack:
         self.lbs_pre_dict = {k: self._label(info["init_bbox"][k], r) for k in self.init_object_ids}
         self.state_pre_dict = {k: list(info["init_bbox"][k]) for k in self.init_object_ids}
         self.out_dict_pre_new, self.obj_ids_new = [], []    # reference frames of objects that appear later (:68-69)
+        self._last_det = {}                                 # get_mask_results is callable on its own, like the reference method
 
     def get_det_results(self, fpn, d_cur, d_pre, object_ids):
         """unicorn_vos.py:157-200 for one reference group: {obj_id: det (N,7) | None}, {obj_id: masks (N,1,Hn,Wn) | None}"""
@@ -72,7 +73,7 @@ class UnicornVOSTrack:
             e_pre = m(feat=f_pre, mode="upsample")
             e_cur = m(feat=f_cur, mode="upsample")
             values = torch.cat([self.lbs_pre_dict[k] for k in object_ids], 0)                 # (K, HW/64): ONE correlation call
-            prec = 0 if getattr(m, "precision", "bf16") == "fp32" else 2       # fp32 MFMA in the exact mode, f16x2 split otherwise
+            prec = 0 if getattr(m, "precision", "f16x2") == "fp32" else 2       # fp32 MFMA in the exact mode, f16x2 split otherwise
             pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), values, precision=prec)
             K = len(object_ids)
             p8, p16, p32 = prior_pyramid(pred.view(1, K, self.dh, self.dw))                   # (1,K,..) pyramid of all objects

@@ -13,12 +13,25 @@ import torch
 from ..ops import mask_resize, mots_overlap_free, rle_encode
 
 
-def mots_threshold(outputs_mask, scale, img_h, img_w, mask_thres=0.30):
-    """outputs_mask (N, 1, Hn, Wn) sigmoid scores of postprocess_inst -> (N, img_h, img_w) uint8 masks (mot_evaluator.py:803-804)"""
+def mots_threshold(outputs_mask, scale, img_h, img_w, mask_thres=0.30, crop=True):
+    """outputs_mask (N, 1, Hn, Wn) sigmoid scores of postprocess_inst -> uint8 masks at the original resolution
+    (mot_evaluator.py:803-804): F.interpolate(scale_factor=1/scale)[:, 0, :img_h, :img_w] > mask_thres.
+    The interpolated map has floor(Hn / scale) x floor(Wn / scale) pixels, which can be ONE SHORT of the image (480 x 854 image at
+    800 x 1280: 1280 / 1.4988 -> 853): the reference then encodes a (480, 853) mask.  crop=True (default) returns exactly that
+    shape, so the RLE strings are the reference's; crop=False returns the zero-padded (N, img_h, img_w) maps the VOS driver
+    uses (unicorn_vos.py:146-150 pastes into a full-size map)."""
+    img_h, img_w = int(img_h), int(img_w)
     if outputs_mask is None or outputs_mask.shape[0] == 0:
         dev = outputs_mask.device if outputs_mask is not None else "cuda"
         return torch.zeros((0, img_h, img_w), dtype=torch.uint8, device=dev)
-    return mask_resize(outputs_mask[:, 0], scale, int(img_h), int(img_w), thr=mask_thres)
+    out = mask_resize(outputs_mask[:, 0], scale, img_h, img_w, thr=mask_thres)
+    if crop:
+        import math
+        ho = min(img_h, int(math.floor(outputs_mask.shape[2] * (1.0 / scale))))      # F.interpolate's output size: floor(in * scale_factor)
+        wo = min(img_w, int(math.floor(outputs_mask.shape[3] * (1.0 / scale))))
+        if ho < img_h or wo < img_w:
+            out = out[:, :ho, :wo].contiguous()
+    return out
 
 
 def mots_rle(masks, order=None):
