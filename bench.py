@@ -138,14 +138,16 @@ class Stream:
             from unicorn_amd.tracker import OmniMOTFrame, QuasiDenseEmbedTracker
             # synthetic weights give obj * cls ~ 1e-4: the score thresholds are set from the score distribution of one frame so that
             # ~200 candidates reach the NMS and the association (documented in DESIGN.md); tracker thresholds follow
-            kw = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
-                      memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
-                      match_metric="bisoftmax")
             with torch.no_grad():
                 o, _ = self.model(self.frames[1])
                 o = o[0] if self.cfg.mask else o
                 sc = (o[0, :, 4] * o[0, :, 5:].max(1)[0]).sort(descending=True)[0]
             self.score_thr = float((sc[199] + sc[200]) / 2)
+            # QuasiDense thresholds at the same relative places of the score distribution as the defaults (0.8 / 0.5) have on a trained
+            # detector: ~30 detections may start a track, ~100 take part in the association (the rest are backdrops)
+            kw = dict(init_score_thr=float(sc[30]), obj_score_thr=float(sc[100]), match_score_thr=0.5, memo_tracklet_frames=10,
+                      memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=float(sc[100]), nms_backdrop_iou_thr=0.3,
+                      nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
             self.omni = OmniMOTFrame(self.model, QuasiDenseEmbedTracker(**kw), (H, W), num_classes=self.cfg.num_classes,
                                      confthre=self.score_thr, nmsthre=0.7, embed_score_thr=self.score_thr)
         if task == "vos":
@@ -529,8 +531,8 @@ def main():
             o_, _ = mm_.model(mm_.frames[1])
             sc_ = (o_[0][0, :, 4] * o_[0][0, :, 5]).sort(descending=True)[0]
             thr_ = float((sc_[63] + sc_[64]) / 2)
-            kw_ = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1, memo_momentum=0.8,
-                       nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+            kw_ = dict(init_score_thr=float(sc_[16]), obj_score_thr=float(sc_[40]), match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+                       memo_momentum=0.8, nms_conf_thr=float(sc_[40]), nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
             mots = OmniMOTSFrame(mm_.model, QuasiDenseEmbedTracker(**kw_), (H, W), num_classes=1, confthre=thr_, nmsthre=0.7, embed_score_thr=thr_,
                                  mask_thres=0.3, d_rate=mm_.cfg.d_rate, timer=StageTimer())
             nrle = [0]

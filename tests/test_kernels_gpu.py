@@ -543,18 +543,21 @@ def pack_weight_h2(L, w):
 
 def test_h2_cast_and_pack_formats(L):
     """hi = f16(x), lo = f16(x - hi): 22 significand bits; tiny values keep an absolute error <= 2^-25 (f16 subnormals are
-    kept, not flushed); |x| up to 2 x 65504 stays finite.  The host packer applies a power-of-two scale and the same split."""
+    kept, not flushed); |x| > 65504 SATURATES at +-65504 (hi = +-65504, lo = 0: never inf / NaN).  The host packer applies a
+    power-of-two scale and the same split."""
     g = torch.Generator().manual_seed(0)
     x = torch.randn(257, 64, generator=g)
-    x[0, :8] = torch.tensor([0.0, 1e-7, -3e-6, 65504.0, 1e5, -1.2e5, 6.1e-5, 1.0])   # beyond 65504 the lo half only extends the RANGE
+    x[0, :8] = torch.tensor([0.0, 1e-7, -3e-6, 65504.0, 1e5, -1.2e9, 6.1e-5, 1.0])   # beyond 65504: saturation
     x[1] *= 1e-3
     x[2] *= 300.0
     dec, hi, lo = h2_decode(cast_h2(L, x.cuda()), 257, 64)
     dec, hi = dec.cpu(), hi.cpu()
-    assert torch.isfinite(dec).all()
+    assert torch.isfinite(dec).all() and torch.isfinite(lo).all()
     assert torch.equal(hi[1:], x[1:].half().float())
-    err = (dec - x).abs()
-    assert (err <= x.abs() * 2.0 ** -21 + 2.0 ** -25).all(), err.max()
+    xs = x.clamp(-65504.0, 65504.0)
+    assert dec[0, 4] == 65504.0 and dec[0, 5] == -65504.0 and lo.cpu()[0, 4] == 0 and lo.cpu()[0, 5] == 0
+    err = (dec - xs).abs()
+    assert (err <= xs.abs() * 2.0 ** -21 + 2.0 ** -25).all(), err.max()
     w = torch.randn(40, 16, 3, 3, generator=g) * 0.02
     Wp, wscale = pack_weight_h2(L, w)
     K = 16 * 9

@@ -251,7 +251,9 @@ int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int 
     UNI_REQUIRE(g.M == M, "gemm_h2: M=%d does not match conv geometry (%d)", M, g.M);
     g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
     g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
-    g.b32 = FMT_H2; g.wscale = wscale; g.dbg = force_cfg / 1000;
+    g.b32 = FMT_H2; g.wscale = wscale; g.dbg = (force_cfg / 1000) % 100;
+    g.splitk = force_cfg / 100000;            // tests / tools: force_cfg = tile cfg + 1000 * ablation bits + 100000 * K ranges (outF must hold the values to add onto)
+    g.force_cfg = force_cfg % 1000;
     API(launch_gemm(g, S(stream)));
 }
 size_t uni_mlp_blob_bytes(int C) { return mlp_fused_supported(C) ? mlp_blob_bytes(C) : 0; }

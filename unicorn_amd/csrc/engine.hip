@@ -574,6 +574,19 @@ static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, i
     return g;
 }
 
+// Single-frame (small M) problems leave most of the 256 CUs without a tile: K ranges of one tile then go to different blocks that add
+// their partial products with fp32 atomics (gemm_h2.hip, GemmArgs::splitk).  Returns the number of K ranges (1 = no split).
+// UNI_NO_SPLITK = A/B switch.
+static int choose_splitk(const uni_ctx* c, const GemmArgs& g) {
+    static const bool off = getenv("UNI_NO_SPLITK") != nullptr;
+    if (off || c->b32 != FMT_H2) return 1;
+    const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, g.N <= 64 ? 64 : 128);
+    const int nk = cdiv(g.K, 32);
+    if (tiles >= 160 || nk < 24 || g.N < 64) return 1;
+    int sk = (int)std::min<long>((384 + tiles - 1) / tiles, nk / 12);      // ~1.5 blocks per CU, at least 12 K steps (384 k) per range
+    return sk >= 2 ? std::min(sk, 16) : 1;
+}
+
 // conv (no act) -> GroupNorm(G) -> act, written to `o`
 static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, float eps, int act, ActPtr A, int lda,
                        int Hin, int Win, int stride, const Out& o, hipStream_t s) {
@@ -582,8 +595,17 @@ static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, 
     GemmArgs g = conv_args(conv, A, lda, Hin, Win, stride, (conv.KH - 1) / 2, B);
     float* raw = wsalloc<float>(c, (size_t)g.M * g.N);
     double* st = next_stats(c, B);
-    g.outF = raw; g.ldf = g.N; g.stats = st; g.cpg = g.N / G;
-    RUN(p_gemm(c, g, s));
+    g.outF = raw; g.ldf = g.N;
+    const int sk = choose_splitk(c, g);
+    if (sk > 1) {     // K ranges accumulate onto a zeroed map; the group sums are taken from the finished map
+        g.splitk = sk;
+        UNI_CHECK_HIP(hipMemsetAsync(raw, 0, (size_t)g.M * g.N * sizeof(float), s));
+        RUN(p_gemm(c, g, s));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_gn_stats(raw, g.N, g.Mper, B, g.N, g.N / G, st, s); }));
+    } else {
+        g.stats = st; g.cpg = g.N / G;
+        RUN(p_gemm(c, g, s));
+    }
     GnApplyArgs a;
     a.x = raw; a.ldx = g.N; a.stats = st; a.gamma = gn.g; a.beta = gn.b; a.eps = eps;
     a.M = g.Mper; a.B = B; a.C = g.N; a.G = G; a.act = act;
@@ -637,7 +659,10 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
     g1.act = ACT_GELU; g1.outB = hid; g1.ldb = 4 * C;
     RUN(p_gemm(c, g1, s));
     GemmArgs g2 = conv_args(b.pw2, hid, 4 * C, M, 1, 1, 0);
-    g2.res = x; g2.ldr = C; g2.outF = x; g2.ldf = C; g2.outB = outB; g2.ldb = C;
+    g2.outF = x; g2.ldf = C;
+    const int sk2 = outB.p ? 1 : choose_splitk(c, g2);
+    if (sk2 > 1) g2.splitk = sk2;                  // x += W2 h + b2 in place: the K ranges add onto the residual stream directly
+    else { g2.res = x; g2.ldr = C; g2.outB = outB; g2.ldb = C; }
     RUN(p_gemm(c, g2, s));
     c->ws_off = mark;        // rowstat is dead once pwconv1 is enqueued (in-order stream)
     return 0;
@@ -868,9 +893,14 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             return _rc ? _rc : -3;                                                             \
         }                                                                                      \
     } while (0)
+    auto hip_rc = [](hipError_t e, const char* what) {      // HIP failures inside the forked region go through RUN (which joins the aux streams)
+        if (e == hipSuccess) return 0;
+        uni_set_error("%s -> %s", what, hipGetErrorString(e));
+        return -2;
+    };
     if (fork) {
-        UNI_CHECK_HIP(hipEventRecord(c->ev_fork, s_main));
-        for (int i = 0; i < 2; ++i) UNI_CHECK_HIP(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+        RUN(hip_rc(hipEventRecord(c->ev_fork, s_main), "hipEventRecord(fork)"));
+        for (int i = 0; i < 2; ++i) RUN(hip_rc(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0), "hipStreamWaitEvent(fork)"));
     }
     const size_t lvl_base = (c->ws_off + 255) & ~(size_t)255;
     const size_t M0 = (size_t)B * HWk[0];
@@ -945,8 +975,8 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     s = s_main;
     if (fork) {
         for (int i = 0; i < 2; ++i) {
-            UNI_CHECK_HIP(hipEventRecord(c->ev_join[i], c->aux[i]));
-            UNI_CHECK_HIP(hipStreamWaitEvent(s_main, c->ev_join[i], 0));
+            RUN(hip_rc(hipEventRecord(c->ev_join[i], c->aux[i]), "hipEventRecord(join)"));
+            RUN(hip_rc(hipStreamWaitEvent(s_main, c->ev_join[i], 0), "hipStreamWaitEvent(join)"));
         }
         c->ws_off = lvl_base + 3 * slice_bytes;
     }

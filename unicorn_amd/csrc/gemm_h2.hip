@@ -135,11 +135,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BKE == 16 ? 2 : 1)) void gemm_h2_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BKE - 1) / BKE;              // the packed weights are zero beyond K (Kpad >= roundup(K, 64))
+    int kt0 = 0, nk = (p.K + BKE - 1) / BKE;           // the packed weights are zero beyond K (Kpad >= roundup(K, 64))
+    if (p.splitk > 1) {                                // split-K: this block owns K steps [kt0, nk) of its tile
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        nk = min(nk, kt0 + per);
+        if (kt0 >= nk) return;
+    }
     const int fr = lane & 31, fh = lane >> 5;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    issue(kt0, 0);
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         __syncthreads();                                   // K slice kt landed (vmcnt(0) + barrier); everyone is done with buf^1
         if (kt + 1 < nk && !(p.dbg & 1)) issue(kt + 1, buf ^ 1);     // dbg 1: ablation, no DMA after slice 0
         if (p.dbg & 2) continue;                                     // dbg 2: ablation, DMA only
@@ -205,6 +211,25 @@ __global__ __launch_bounds__(64 * WM * WN, (BKE == 16 ? 2 : 1)) void gemm_h2_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.wscale;
     }
+    if (!STATS && p.splitk > 1) {   // partial product of one K range: fp32 atomic adds onto outF (zeros or the residual), the bias comes with range 0
+        const bool first = blockIdx.y == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * 32 * TM + i * 32 + fr;
+            if (row >= p.M) continue;
+            const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = n0 + wn * 32 * TN + j * 32 + 8 * g + 4 * fh + e;
+                        if (col < p.N) atomicAdd(p.outF + (size_t)orow * p.ldf + col, acc[i][j][4 * g + e] + ((first && p.bias) ? p.bias[col] : 0.f));
+                    }
+        }
+        return;
+    }
     gemm_epilogue<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
@@ -212,6 +237,7 @@ template <int WM, int WN, int TM, int TN, bool CONV, int BKE = 32>
 static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const int gy = a.splitk > 1 ? a.splitk : 1;
     size_t lds = (size_t)2 * (BM + BN) * 4 * BKE;
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
@@ -222,7 +248,7 @@ static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
         attr_done = true;
     }
     if (a.stats) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
-    else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), dim3(grid, gy), dim3(64 * WM * WN), lds, s, a);
     return 0;
 }
 
@@ -247,6 +273,11 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     const long b12 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
     const double util44 = (double)a.N / (cdiv(a.N, 256) * 256.0);
     int cfg = a.force_cfg % 1000;
+    if (a.splitk > 1) {
+        UNI_REQUIRE(a.outF && !a.outB && !a.stats && !a.res && a.act == ACT_NONE && !a.rowstat, "gemm(h2): split-K adds fp32 partial products onto outF only");
+        UNI_REQUIRE(a.splitk <= 64, "gemm(h2): splitk=%d", a.splitk);
+        if (cfg == 0 || cfg == 44 || cfg == 48 || cfg == 42 || cfg == 188 || cfg == 144) cfg = (a.N <= 64) ? 21 : 22;      // 128 x 128 (128 x 64) tiles, several K ranges each
+    }
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
         else if (util44 >= 0.74 && b44 >= 384 && a.epi) cfg = 44;

@@ -24,6 +24,9 @@ struct GemmArgs {
     // LayerNorm of the A rows folded into the epilogue: v = rstd[m] * (acc - mean[m] * colsum[n]) (+ bias): rowstat [M][2] = (mean, rstd)
     // from dwconv7_raw, colsum [N] = row sums of the packed weights (which carry the LN gamma), bias = b + W beta
     const float* rowstat = nullptr; const float* colsum = nullptr;
+    int splitk = 0;                           // FMT_H2, > 1: the K loop is cut into `splitk` ranges (gridDim.y); every range ADDS its partial product to outF with fp32
+                                              // atomics (range 0 also adds the bias): outF must hold the value to accumulate onto (zeros, or the residual for in-place
+                                              // x += W h); no activation / residual pointer / operand-format output / GroupNorm statistics in this mode
     int dbg = 0;                              // ablation switches for tools/gemm_bench.py (1 = no DMA after tile 0, 2 = no MFMA)
     int epi = 0;                              // set by launch_gemm: 1 = LDS-staged, row-coalesced epilogue stores
 };
@@ -89,6 +92,9 @@ struct GnApplyArgs {
     int b32 = 0;
 };
 int launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
+// GroupNorm group sums of a finished fp32 map (split-K convolutions cannot take them in their epilogue): x [B * M][ldx], C channels in groups of cpg
+// -> stats[b * 64 + 2 g + {0, 1}] += (sum, sum of squares)
+int launch_gn_stats(const float* x, int ldx, int M, int B, int C, int cpg, double* stats, hipStream_t s);
 
 // depthwise 7x7 (+bias) + LayerNorm(C): fp32 NHWC -> bf16 [M][C]
 struct DwLnArgs {
