@@ -957,3 +957,47 @@ def test_mots_threshold_matches_reference_crop_shape():
     assert (got.cpu().bool() != ref).float().mean() < 1e-5            # thresholding an fp32 interpolation: ties at round-off only
     full = mots_threshold(om.cuda(), scale, img_h, img_w, 0.3, crop=False)
     assert tuple(full.shape) == (3, img_h, img_w) and not full[:, :, img_w - 1:].any()
+
+
+@pytest.mark.parametrize("case", [
+    # (Hin, Win, Cin, N, k, res, stats_G, splitk, cfg)
+    (25, 40, 256, 256, 3, False, 16, 4, 0),          # head tower conv at stride 32, GroupNorm sums from the reduce kernel
+    (50, 80, 384, 384, 3, False, 16, 2, 22),
+    (1000, 1, 3072, 768, 1, True, 0, 3, 0),          # pwconv2 + in-place residual, ragged M, K ranges of unequal length
+    (130, 1, 1536, 64, 1, False, 0, 8, 0),           # N = 64: 128 x 64 tiles
+    (4000, 1, 3072, 768, 1, True, 0, 4, 188),        # stage-2 pwconv2 of one frame: K ranges as work units of the ping-pong kernel
+    (100, 160, 256, 256, 3, False, 16, 4, 188),      # head tower 3x3 conv, ping-pong implicit GEMM, statistics in the reduce
+    (25, 40, 768, 768, 3, False, 16, 6, 0),          # heuristic takes the ping-pong kernel (K steps divisible by the split)
+    (50, 80, 384, 384, 3, False, 16, 3, 188),        # ragged M tile (4000 rows), 108 K steps / 3
+])
+def test_gemm_h2_splitk(L, case):
+    """Split-K of the single-frame path (gemm_h2.hip): K ranges -> partial-tile slab -> splitk_reduce_kernel (bias, residual, GroupNorm
+    sums) must equal the unsplit launch of the same problem to fp32 round-off, and torch fp64 to the f16x2 bound."""
+    Hin, Win, Cin, N, k, use_res, G, sk, cfg = case
+    g = torch.Generator().manual_seed(Hin + N + sk)
+    pad = (k - 1) // 2
+    M, K = Hin * Win, Cin * k * k
+    x = torch.randn(1, Cin, Hin, Win, generator=g)
+    w = torch.randn(N, Cin, k, k, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    A = cast_h2(L, x[0].permute(1, 2, 0).reshape(M, Cin).contiguous().cuda())
+    Wp, ws = pack_weight_h2(L, w)
+    res0 = torch.randn(M, N, generator=g).cuda()
+    outs, stats = [], []
+    for split in (1, sk):
+        out = res0.clone() if use_res else torch.zeros((M, N), device="cuda")
+        st = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
+        L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), ws, M, N, Hin, Win, Cin, k, k, 1, pad, L.ptr(bias.cuda()) if True else None, 0,
+                                    L.ptr(out) if use_res else None, N, L.ptr(out), N, None, 0, L.ptr(st), N // G if G else 0,
+                                    cfg + (100000 * split if split > 1 else 0), L.stream_ptr()), "gemm_h2")
+        torch.cuda.synchronize()
+        outs.append(out.cpu().double())
+        stats.append(None if st is None else st.cpu())
+    ref = F.conv2d(h2_decode(A, M, Cin)[0].cpu().double().reshape(Hin, Win, Cin).permute(2, 0, 1)[None], w.double(), bias.double(), padding=pad)
+    ref = ref[0].permute(1, 2, 0).reshape(M, N) + (res0.cpu().double() if use_res else 0)
+    scale = max(1.0, ref.abs().max().item())
+    tol = 4e-6 if K <= 4096 else 1e-5                     # fp32 accumulation over K terms
+    assert (outs[1] - ref).abs().max() < tol * scale
+    assert (outs[1] - outs[0]).abs().max() < tol * scale
+    if G:
+        assert (stats[1][:2 * G] - stats[0][:2 * G]).abs().max() < 1e-5 * stats[0][:2 * G].abs().max()

@@ -252,8 +252,22 @@ int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int 
     g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
     g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
     g.b32 = FMT_H2; g.wscale = wscale; g.dbg = (force_cfg / 1000) % 100;
-    g.splitk = force_cfg / 100000;            // tests / tools: force_cfg = tile cfg + 1000 * ablation bits + 100000 * K ranges (outF must hold the values to add onto)
+    g.splitk = force_cfg / 100000;            // tests / tools: force_cfg = tile cfg + 1000 * ablation bits + 100000 * K ranges
     g.force_cfg = force_cfg % 1000;
+    g.Mper = g.M;
+    if (g.splitk > 1) {                       // partial-tile slab of the split-K path: one grow-only buffer for this test / bench entry
+        static float* slab = nullptr;
+        static size_t cap = 0;
+        const size_t need = (size_t)g.splitk * g.M * g.N * sizeof(float);
+        if (need > cap) {
+            UNI_CHECK_HIP(hipDeviceSynchronize());
+            if (slab) (void)hipFree(slab);
+            slab = nullptr; cap = 0;
+            UNI_CHECK_HIP(hipMalloc(&slab, need));
+            cap = need;
+        }
+        g.slab = slab;
+    }
     API(launch_gemm(g, S(stream)));
 }
 size_t uni_mlp_blob_bytes(int C) { return mlp_fused_supported(C) ? mlp_blob_bytes(C) : 0; }

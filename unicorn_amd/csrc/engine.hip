@@ -579,12 +579,19 @@ static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, i
 // UNI_NO_SPLITK = A/B switch.
 static int choose_splitk(const uni_ctx* c, const GemmArgs& g) {
     static const bool off = getenv("UNI_NO_SPLITK") != nullptr;
-    if (off || c->b32 != FMT_H2) return 1;
-    const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, g.N <= 64 ? 64 : 128);
-    const int nk = cdiv(g.K, 32);
-    if (tiles >= 160 || nk < 24 || g.N < 64) return 1;
-    int sk = (int)std::min<long>((384 + tiles - 1) / tiles, nk / 12);      // ~1.5 blocks per CU, at least 12 K steps (384 k) per range
-    return sk >= 2 ? std::min(sk, 16) : 1;
+    if (off || c->b32 != FMT_H2 || g.N < 128 || g.N % 4 != 0 || g.K % 32 != 0) return 1;
+    const bool conv = g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad != 0;
+    const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    const int nk = g.K / 32;
+    // tools/gemm_b1_bench.py on the single-frame shapes: 3x3 convolutions gain 25-50 % from ~400 blocks of >= 12 K steps (4000 x 384 x 3456:
+    // 79 -> 60 us with 4 ranges, 1000 x 768 x 6912: 140 -> 69 us with 8); plain GEMMs only with very long K and few tiles (1000 x 1536 x 6144:
+    // 107 -> 94 us); 1x1 convolutions and the stage-2 MLP (N >= 768, hundreds of 64 x 64 tiles) do not
+    if (conv) {
+        if (tiles > 128 || nk < 24) return 1;
+        int sk = (int)std::min<long>((400 + tiles / 2) / tiles, nk / 12);
+        return sk >= 2 ? std::min(sk, 8) : 1;
+    }
+    return (tiles <= 96 && nk >= 192) ? 4 : 1;
 }
 
 // conv (no act) -> GroupNorm(G) -> act, written to `o`
@@ -596,16 +603,10 @@ static int run_conv_gn(uni_ctx* c, const PConv& conv, const PAffine& gn, int G, 
     float* raw = wsalloc<float>(c, (size_t)g.M * g.N);
     double* st = next_stats(c, B);
     g.outF = raw; g.ldf = g.N;
+    g.stats = st; g.cpg = g.N / G;
     const int sk = choose_splitk(c, g);
-    if (sk > 1) {     // K ranges accumulate onto a zeroed map; the group sums are taken from the finished map
-        g.splitk = sk;
-        UNI_CHECK_HIP(hipMemsetAsync(raw, 0, (size_t)g.M * g.N * sizeof(float), s));
-        RUN(p_gemm(c, g, s));
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_gn_stats(raw, g.N, g.Mper, B, g.N, g.N / G, st, s); }));
-    } else {
-        g.stats = st; g.cpg = g.N / G;
-        RUN(p_gemm(c, g, s));
-    }
+    if (sk > 1) { g.splitk = sk; g.slab = wsalloc<float>(c, (size_t)sk * g.M * g.N); }     // K ranges -> slab -> reduce (+ bias, group sums)
+    RUN(p_gemm(c, g, s));
     GnApplyArgs a;
     a.x = raw; a.ldx = g.N; a.stats = st; a.gamma = gn.g; a.beta = gn.b; a.eps = eps;
     a.M = g.Mper; a.B = B; a.C = g.N; a.G = G; a.act = act;
@@ -659,10 +660,9 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
     g1.act = ACT_GELU; g1.outB = hid; g1.ldb = 4 * C;
     RUN(p_gemm(c, g1, s));
     GemmArgs g2 = conv_args(b.pw2, hid, 4 * C, M, 1, 1, 0);
-    g2.outF = x; g2.ldf = C;
+    g2.res = x; g2.ldr = C; g2.outF = x; g2.ldf = C; g2.outB = outB; g2.ldb = C;
     const int sk2 = outB.p ? 1 : choose_splitk(c, g2);
-    if (sk2 > 1) g2.splitk = sk2;                  // x += W2 h + b2 in place: the K ranges add onto the residual stream directly
-    else { g2.res = x; g2.ldr = C; g2.outB = outB; g2.ldb = C; }
+    if (sk2 > 1) { g2.splitk = sk2; g2.slab = wsalloc<float>(c, (size_t)sk2 * M * C); }
     RUN(p_gemm(c, g2, s));
     c->ws_off = mark;        // rowstat is dead once pwconv1 is enqueued (in-order stream)
     return 0;

@@ -211,26 +211,75 @@ __global__ __launch_bounds__(64 * WM * WN, (BKE == 16 ? 2 : 1)) void gemm_h2_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.wscale;
     }
-    if (!STATS && p.splitk > 1) {   // partial product of one K range: fp32 atomic adds onto outF (zeros or the residual), the bias comes with range 0
-        const bool first = blockIdx.y == 0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * 32 * TM + i * 32 + fr;
-            if (row >= p.M) continue;
-            const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int col = n0 + wn * 32 * TN + j * 32 + 8 * g + 4 * fh + e;
-                        if (col < p.N) atomicAdd(p.outF + (size_t)orow * p.ldf + col, acc[i][j][4 * g + e] + ((first && p.bias) ? p.bias[col] : 0.f));
-                    }
-        }
+    if (!STATS && p.splitk > 1) {   // partial product of one K range -> its slab; bias / residual / statistics belong to the reduce kernel
+        GemmArgs q = p;
+        q.outF = p.slab + (size_t)blockIdx.y * p.M * p.N; q.ldf = p.N;
+        q.bias = nullptr; q.res = nullptr; q.outB = nullptr; q.stats = nullptr; q.out_hw = 0; q.act = ACT_NONE;
+        gemm_epilogue<WM, WN, TM, TN, false>(q, acc, m0, n0, wm, wn, lane, tid, smem);
         return;
     }
     gemm_epilogue<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+// split-K reduce: out[m][n] = sum_s slab[s][m][n] + bias[n] (+ res[m][n]); optional GroupNorm group sums of the result per sample.
+// Block = RB rows of ONE sample x all N columns (thread -> float4 column groups); the RB x splitk loads of a thread are independent
+// (the first version walked 32 rows x splits serially per thread: latency-bound, slower than the GEMM it served).
+constexpr int RED_RB = 8;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
+    __shared__ float gacc[64];
+    const int sb = blockIdx.y, r0 = blockIdx.x * RED_RB;
+    if (p.stats) {
+        if (threadIdx.x < 64) gacc[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
+    const size_t MN = (size_t)p.M * p.N;
+    for (int c = threadIdx.x * 4; c < p.N; c += 1024) {
+        f32x4 v[RED_RB];
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + c);
+#pragma unroll
+        for (int i = 0; i < RED_RB; ++i) v[i] = bv;
+        for (int k = 0; k < p.splitk; ++k) {
+            const float* sk = p.slab + k * MN + ((size_t)sb * p.Mper + r0) * p.N + c;
+#pragma unroll
+            for (int i = 0; i < RED_RB; ++i)
+                if (r0 + i < p.Mper) v[i] += *reinterpret_cast<const f32x4*>(sk + (size_t)i * p.N);
+        }
+        f32x4 s_ = {0.f, 0.f, 0.f, 0.f}, q_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < RED_RB; ++i) {
+            if (r0 + i >= p.Mper) break;
+            const size_t row = (size_t)sb * p.Mper + r0 + i;
+            if (p.stats) { s_ += v[i]; q_ += v[i] * v[i]; }
+            f32x4 o = v[i];
+            if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + c);
+            *reinterpret_cast<f32x4*>(p.outF + row * p.ldf + c) = o;
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = (c + e) / p.cpg;
+                atomicAdd(&gacc[2 * g], s_[e]);
+                atomicAdd(&gacc[2 * g + 1], q_[e]);
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        const int G = p.N / p.cpg;
+        if ((int)threadIdx.x < 2 * G) atomicAdd(&p.stats[(size_t)sb * 64 + threadIdx.x], (double)gacc[threadIdx.x]);
+    }
+}
+
+GemmArgs gemm_splitk_partial_args(const GemmArgs& a) {
+    GemmArgs g = a;
+    g.outF = a.slab; g.ldf = a.N;
+    g.bias = nullptr; g.res = nullptr; g.ldr = 0; g.outB = nullptr; g.stats = nullptr; g.cpg = 0; g.out_hw = 0; g.act = ACT_NONE;
+    return g;
+}
+int launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(a.Mper, RED_RB), a.M / a.Mper), dim3(256), 0, s, a);
+    return 0;
 }
 
 template <int WM, int WN, int TM, int TN, bool CONV, int BKE = 32>
@@ -247,8 +296,9 @@ static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (a.stats) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
+    if (a.stats && gy == 1) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), dim3(grid, gy), dim3(64 * WM * WN), lds, s, a);
+    if (gy > 1) return launch_splitk_reduce(a, s);
     return 0;
 }
 
@@ -274,9 +324,22 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     const double util44 = (double)a.N / (cdiv(a.N, 256) * 256.0);
     int cfg = a.force_cfg % 1000;
     if (a.splitk > 1) {
-        UNI_REQUIRE(a.outF && !a.outB && !a.stats && !a.res && a.act == ACT_NONE && !a.rowstat, "gemm(h2): split-K adds fp32 partial products onto outF only");
-        UNI_REQUIRE(a.splitk <= 64, "gemm(h2): splitk=%d", a.splitk);
-        if (cfg == 0 || cfg == 44 || cfg == 48 || cfg == 42 || cfg == 188 || cfg == 144) cfg = (a.N <= 64) ? 21 : 22;      // 128 x 128 (128 x 64) tiles, several K ranges each
+        UNI_REQUIRE(a.outF && a.slab && !a.outB && a.act == ACT_NONE && !a.rowstat && !a.out_hw, "gemm(h2): split-K needs fp32 output + a slab, no activation / operand-format output");
+        UNI_REQUIRE(a.splitk <= 64 && a.N % 4 == 0 && a.ldf % 4 == 0 && (!a.res || a.ldr % 4 == 0) && a.Mper > 0 && a.M % a.Mper == 0 && a.epi,
+                    "gemm(h2): splitk=%d N=%d ldf=%d Mper=%d", a.splitk, a.N, a.ldf, a.Mper);
+        if (a.stats) UNI_REQUIRE(a.cpg > 0 && a.N % a.cpg == 0 && a.N / a.cpg <= 32, "gemm(h2): split-K statistics cpg=%d", a.cpg);
+        // the persistent ping-pong kernel runs the K ranges as work units (its deep DMA stream is what small-M problems lack: the
+        // generic tiles pay a full load latency per K step); everything it does not cover takes 128 x 128 (128 x 64) tiles
+        // (measured, tools/gemm_b1_bench.py: implicit GEMMs do better on the 128 x 128 tiles, plain GEMMs with long K on the ping-pong kernel)
+        if ((cfg == 0 && !conv && a.K >= 6144) || cfg == 188) {
+            GemmArgs g = gemm_splitk_partial_args(a);
+            g.splitk = 0;
+            const int nks = a.K / 32;
+            static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;
+            if (!no_q && a.N > 64 && a.K % 32 == 0 && nks % a.splitk == 0 && nks / a.splitk >= 2 && gemm_h2q_supported(g)) return launch_gemm_h2q(a, s);
+            UNI_REQUIRE(cfg != 188, "gemm(h2): ping-pong split-K does not support this problem");
+        }
+        if (cfg == 0 || cfg == 44 || cfg == 48 || cfg == 42 || cfg == 188 || cfg == 144) cfg = (a.N <= 64) ? 21 : 22;
     }
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;

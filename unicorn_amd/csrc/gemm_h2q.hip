@@ -33,18 +33,21 @@ constexpr int OPER = 2 * STAGE;
 constexpr int STG = 4096;                        // per-wave epilogue staging block
 constexpr int LDS_BYTES = OPER + NW * STG;       // 163840 = all of the CU's LDS
 
-struct Tile { int m0, n0; };
+struct Tile { int m0, n0, k0, split; };      // k0: first K step of the unit (split-K), split: index of its K range
 // A side of a tile: buffer descriptor + per-lane offsets [half][piece]; CONV: byte offset (< 2^26, launcher checks) | validity bits << 26.
 // (At namespace scope: a struct local to the kernel template makes hipcc drop the host stubs of its instantiations.)
 struct ATile { __amdgpu_buffer_rsrc_t rs; int vo[2][2]; };
-__device__ __forceinline__ Tile tile_of(int L, int nbm, int nbn) {
+// unit u of a split-K launch = (K range u / ntiles, tile u % ntiles): neighbouring units are different tiles of the same K range (shared panels)
+__device__ __forceinline__ Tile tile_of(int u, int nbm, int nbn, int nku) {
+    const int ntiles = nbm * nbn;
+    const int split = u / ntiles, L = u - split * ntiles;
     constexpr int GN = 8;           // N is cut into chunks of 8 tiles; inside a chunk tiles run M-major (see gemm.hip)
     const int per_chunk = nbm * GN;
     const int c = L / per_chunk;
     const int wc = min(GN, nbn - c * GN);
     const int rem = L - c * per_chunk;
     const int bm = rem / wc;
-    return {bm * BM, (c * GN + rem - bm * wc) * BN};
+    return {bm * BM, (c * GN + rem - bm * wc) * BN, split * nku, split};
 }
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     int first, stride, count;
     {
-        const int ntiles = nbm * nbn;
+        const int ntiles = nbm * nbn * (p.splitk > 1 ? p.splitk : 1);      // work units
         const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
         const int q = ntiles >> 3, r = ntiles & 7;
         const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     // fragment registers [.][0..3]: f16x2 = (hi, lo) of k slice 0, (hi, lo) of k slice 1; bf16 = k slices 0..3.  B fragments of both
     // halves stay in registers (B0 serves phases 1 and 4)
     f16x8 fa[2][4], fb[2][4];
-    const int nk = p.K / KS;
-    Tile cur = tile_of(first, nbm, nbn);
-    Tile nxt = count > 1 ? tile_of(first + stride, nbm, nbn) : cur;
+    const int nk = (p.K / KS) / (p.splitk > 1 ? p.splitk : 1);       // K steps per unit (the launcher makes the split divide the K steps)
+    Tile cur = tile_of(first, nbm, nbn, nk);
+    Tile nxt = count > 1 ? tile_of(first + stride, nbm, nbn, nk) : cur;
     ATile ta_cur, ta_nxt;
     make_a(cur, ta_cur);
     make_a(nxt, ta_nxt);
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     int fk = kt + (ahead);                                             \
     const bool fnx = fk >= nk;                                         \
     fk -= fnx ? nk : 0;                                                \
+    fk += fnx ? nxt.k0 : cur.k0;              /* absolute K step: the unit's K range starts at k0 */ \
     const __amdgpu_buffer_rsrc_t fb = fnx ? rb_nxt : rb_cur;                                  \
     ATile fa;                                                                                  \
     fa.rs = fnx ? ta_nxt.rs : ta_cur.rs;                                                       \
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
     // ---- prologue: step 0 completely, step 1 without its B0 (phase 1 of step 0 requests that one)
     {
         const int kt = 0;
-        issueA(0, 0, 0, ta_cur); issueB(0, 0, 0, rb_cur); issueB(1, 0, 0, rb_cur); issueA(1, 0, 0, ta_cur);
+        issueA(0, 0, cur.k0, ta_cur); issueB(0, 0, cur.k0, rb_cur); issueB(1, 0, cur.k0, rb_cur); issueA(1, 0, cur.k0, ta_cur);
         Q_FUT(1);
         issueA(0, 1, fk, fa); issueB(1, 1, fk, fb); issueA(1, 1, fk, fa);
     }
@@ -293,10 +297,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
         // ---- tile done (the DMA stream is already inside the next tile)
         const Tile done = cur;
         cur = nxt; ta_cur = ta_nxt; rb_cur = rb_nxt;
-        if (t + 2 < count) { nxt = tile_of(first + (t + 2) * stride, nbm, nbn); make_a(nxt, ta_nxt); rb_nxt = rsrc_b(nxt); }
+        if (t + 2 < count) { nxt = tile_of(first + (t + 2) * stride, nbm, nbn, nk); make_a(nxt, ta_nxt); rb_nxt = rsrc_b(nxt); }
         char* st = smem + OPER + wave * STG;
         const int nw0 = done.n0 + wc * 64;
         const int rb0 = done.m0 + grp * 128;
+        const int srow = p.splitk > 1 ? done.split * p.M : 0;     // split-K: outF is the slab [splitk][M][N], this unit's K range owns slab `split`
         if (p.dbg & 16) {                             // ablation: no drain, accumulators kept live
             float sacc = 0.f;
 #pragma unroll
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 128 + ((c ^ (r & 7)) << 4));
                         if (has_res) v += rv[tt];
                         if (row < p.M && col < p.N && !(p.dbg & 4)) {
-                            const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;
+                            const int orow = (p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row) + srow;
                             *reinterpret_cast<f32x4*>(p.outF + (size_t)orow * p.ldf + col) = v;
                             if (has_b) act_store4(p.outB, (size_t)row * p.ldb + col, v[0], v[1], v[2], v[3], FMT);
                         }
@@ -450,7 +455,10 @@ bool gemm_h2q_supported(const GemmArgs& a) {
     if (a.b32 != FMT_H2 && a.b32 != FMT_BF16) return false;
     const int ks = a.b32 == FMT_H2 ? 32 : 64, eb = a.b32 == FMT_H2 ? 4 : 2;
     if (!a.epi || a.K % ks != 0 || a.K < 2 * ks || a.rowstat || a.act_col0 != 0) return false;
-    if (!conv && !a.stats) return a.b32 == FMT_H2 ? gemm_h2p_supported(a) : gemm_p44_supported(a);
+    if (!conv && !a.stats) {
+        if (a.b32 != FMT_H2) return gemm_p44_supported(a);
+        return a.out_hw == 0 && (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_GELU) && (a.outF || a.outB) && (a.outF || !a.res);   // (bias optional)
+    }
     if (conv) {
         if (a.Cin % ks != 0 || a.KH > 3 || a.KW > 3 || a.K != a.KH * a.KW * a.Cin || a.Cin / ks > 448) return false;
         // the input pixels of one 256-row tile must lie within 2^26 bytes of its first one (the per-lane offsets carry 6 flag bits)
@@ -487,7 +495,13 @@ int launch_gemm_h2q(const GemmArgs& a, hipStream_t s) {
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         ncu -= ncu % 8;
     }
-    const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const int sk = a.splitk > 1 ? a.splitk : 1;
+    const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN) * sk;
     const int grid = ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu;
+    if (sk > 1) {     // K ranges -> slab [sk][M][N]; bias / residual / GroupNorm sums are applied by the reduce kernel (gemm_h2.hip)
+        GemmArgs g = gemm_splitk_partial_args(a);
+        int rc = launch_h2q_fmt<FMT_H2>(g, grid, s);
+        return rc ? rc : launch_splitk_reduce(a, s);
+    }
     return a.b32 == FMT_H2 ? launch_h2q_fmt<FMT_H2>(a, grid, s) : launch_h2q_fmt<FMT_BF16>(a, grid, s);
 }

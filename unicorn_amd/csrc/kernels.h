@@ -24,9 +24,10 @@ struct GemmArgs {
     // LayerNorm of the A rows folded into the epilogue: v = rstd[m] * (acc - mean[m] * colsum[n]) (+ bias): rowstat [M][2] = (mean, rstd)
     // from dwconv7_raw, colsum [N] = row sums of the packed weights (which carry the LN gamma), bias = b + W beta
     const float* rowstat = nullptr; const float* colsum = nullptr;
-    int splitk = 0;                           // FMT_H2, > 1: the K loop is cut into `splitk` ranges (gridDim.y); every range ADDS its partial product to outF with fp32
-                                              // atomics (range 0 also adds the bias): outF must hold the value to accumulate onto (zeros, or the residual for in-place
-                                              // x += W h); no activation / residual pointer / operand-format output / GroupNorm statistics in this mode
+    // FMT_H2, single-frame problems (few tiles): splitk > 1 cuts the K loop into `splitk` ranges (gridDim.y); every range stores its partial
+    // tile into slab [splitk][M][N] fp32 and a reduce kernel (launched by launch_gemm_h2) sums the ranges and applies bias / residual /
+    // GroupNorm sums -> outF.  No activation, no operand-format output in this mode.
+    int splitk = 0; float* slab = nullptr;
     int dbg = 0;                              // ablation switches for tools/gemm_bench.py (1 = no DMA after tile 0, 2 = no MFMA)
     int epi = 0;                              // set by launch_gemm: 1 = LDS-staged, row-coalesced epilogue stores
 };
@@ -41,6 +42,8 @@ int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persi
 bool gemm_p44_supported(const GemmArgs& a);
 int launch_gemm_h2p(const GemmArgs& a, hipStream_t s);    // gemm_h2p.hip: the same for the split-f16 format
 bool gemm_h2p_supported(const GemmArgs& a);
+GemmArgs gemm_splitk_partial_args(const GemmArgs& a);    // the launch that fills the slab: fp32 partial tiles only (no bias / residual / statistics / remap)
+int launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 int launch_gemm_h2q(const GemmArgs& a, hipStream_t s);    // gemm_h2q.hip: persistent 256x256, two wave groups ping-pong MFMA / LDS phases, counted-vmcnt DMA stream
 bool gemm_h2q_supported(const GemmArgs& a);
 
@@ -92,9 +95,6 @@ struct GnApplyArgs {
     int b32 = 0;
 };
 int launch_gn_apply(const GnApplyArgs& a, hipStream_t s);
-// GroupNorm group sums of a finished fp32 map (split-K convolutions cannot take them in their epilogue): x [B * M][ldx], C channels in groups of cpg
-// -> stats[b * 64 + 2 g + {0, 1}] += (sum, sum of squares)
-int launch_gn_stats(const float* x, int ldx, int M, int B, int C, int cpg, double* stats, hipStream_t s);
 
 // depthwise 7x7 (+bias) + LayerNorm(C): fp32 NHWC -> bf16 [M][C]
 struct DwLnArgs {

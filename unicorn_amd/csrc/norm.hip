@@ -154,31 +154,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     }
 }
 
-// GroupNorm group sums of a finished fp32 map (the split-K convolutions of the single-frame path cannot take them in their epilogue).
-// Block = 64 rows of one sample; thread t walks channels t, t + 256, ...; per-channel sums -> per-group sums in LDS -> fp64 atomics.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ldx, int M, int C, int cpg, double* stats) {
-    __shared__ float gacc[64];
-    const int sb = blockIdx.y, r0 = blockIdx.x * 64, r1 = min(M, r0 + 64);
-    if (threadIdx.x < 64) gacc[threadIdx.x] = 0.f;
-    __syncthreads();
-    const float* xb = x + ((size_t)sb * M) * ldx;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s_ = 0.f, q_ = 0.f;
-        for (int r = r0; r < r1; ++r) { const float v = xb[(size_t)r * ldx + c]; s_ += v; q_ += v * v; }
-        const int g = c / cpg;
-        atomicAdd(&gacc[2 * g], s_);
-        atomicAdd(&gacc[2 * g + 1], q_);
-    }
-    __syncthreads();
-    const int G = C / cpg;
-    if ((int)threadIdx.x < 2 * G) atomicAdd(&stats[(size_t)sb * 64 + threadIdx.x], (double)gacc[threadIdx.x]);
-}
-int launch_gn_stats(const float* x, int ldx, int M, int B, int C, int cpg, double* stats, hipStream_t s) {
-    UNI_REQUIRE(x && stats && cpg > 0 && C % cpg == 0 && C / cpg <= 32 && M > 0 && B > 0, "gn_stats: C=%d cpg=%d M=%d B=%d", C, cpg, M, B);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(M, 64), B), dim3(256), 0, s, x, ldx, M, C, cpg, stats);
-    return 0;
-}
-
 int launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     UNI_REQUIRE(a.C % 8 == 0 && a.C % a.G == 0 && a.ldx % 4 == 0, "gn_apply: C=%d G=%d ldx=%d", a.C, a.G, a.ldx);
     if (a.outB) UNI_REQUIRE(a.ldb % 8 == 0 && ((uintptr_t)a.outB & 15) == 0, "gn_apply: outB alignment");
