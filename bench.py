@@ -570,6 +570,21 @@ def main():
                 parity["vos_best_box_iou_min"] = round(min(bi), 6)
                 parity["pass"] = bool(parity["pass"] and min(mi) >= 0.999)
             configs["large_vos_k3"]["parity"] = {"mask_iou_min": min(mi) if mi else None, "best_box_iou_min": min(bi) if bi else None}
+        # (d) VOS with 16 objects in one reference group: ONE correlation pass (16 value rows) + ONE object-batched head call
+        with torch.no_grad():
+            trk16 = vs.trk
+            bx16 = {str(k_ + 1): [W * (0.05 + 0.22 * (k_ % 4)), H * (0.05 + 0.22 * (k_ // 4)), W * 0.18, H * 0.18] for k_ in range(16)}
+            trk16.initialize(vs.frames[0], {"init_object_ids": list(bx16), "init_bbox": bx16})
+            for i in range(2):
+                trk16.step(vs.frames[1 + i])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(5):
+                trk16.step(vs.frames[1 + i % 4])
+            torch.cuda.synchronize()
+            d16 = (time.perf_counter() - t1) / 5
+        configs["large_vos_k16"] = {"fps": round(1.0 / d16, 2), "ms_per_frame": round(1e3 * d16, 3), "frames_per_step": 1, "precision": args.precision,
+                                    "note": "16 objects per frame (UnicornVOSTrack.step): one backbone, one 16-row correlation pass, one object-batched head call, CondInst masks"}
 
     if rank == 0:
         nf = main_s.frames_per_step()

@@ -325,7 +325,7 @@ def test_msda_random_vs_oracle(L):
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
-@pytest.mark.parametrize("R,Q,K", [(1600, 1600, 1), (1000, 1300, 3), (4000, 2000, 5), (333, 257, 9)])
+@pytest.mark.parametrize("R,Q,K", [(1600, 1600, 1), (1000, 1300, 3), (4000, 2000, 5), (333, 257, 9), (1500, 1100, 16), (700, 900, 21)])
 def test_corr_softmax_pv(L, R, Q, K, prec):
     from unicorn_amd.ops import corr_softmax_pv
     g = torch.Generator().manual_seed(R + Q)

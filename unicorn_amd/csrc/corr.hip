@@ -569,6 +569,9 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
         size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
         hipLaunchKernelGGL((corr_h2_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
                            Q, K, ns_eff, rps);
+    } else if constexpr (KV > 8) {
+        uni_set_error("corr: 16 value rows per pass only in precision 2 / 3");
+        return -1;
     } else if (precision) {
         size_t lds = (size_t)2 * 3 * TR * CD * sizeof(bf16) + (size_t)2 * KV * TR * sizeof(float);
         hipLaunchKernelGGL((corr_split_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
@@ -587,7 +590,7 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
 size_t corr_workspace_bytes(int R, int Q, int K) {
     (void)K;
     const int a = pick_nsplit(R, Q, 0), b = pick_nsplit(R, Q, 1);
-    return (size_t)(a > b ? a : b) * Q * (2 + 8) * sizeof(float);
+    return (size_t)(a > b ? a : b) * Q * (2 + 16) * sizeof(float);
 }
 
 int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,
@@ -598,12 +601,16 @@ int launch_corr(const float* eref, const float* ecur, const float* v, float* out
     UNI_REQUIRE(ws_bytes >= corr_workspace_bytes(R, Q, K), "corr: workspace too small");
     UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
     float* ws = reinterpret_cast<float*>(workspace);
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        const int kc = K - k0 < 8 ? K - k0 : 8;
+    // value rows (objects) in chunks of up to 16: every chunk re-evaluates the R x Q scores, so a VOS group of 9..16 objects
+    // (unicorn_vos.py:166-186) costs ONE pass instead of two
+    const int chunk = (precision >= 2) ? 16 : 8;      // the 16-row instantiation of the bf16x3 / exact-fp32 kernels spills: they keep 8
+    for (int k0 = 0; k0 < K; k0 += chunk) {
+        const int kc = K - k0 < chunk ? K - k0 : chunk;
         int rc;
         if (kc == 1) rc = run<1>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
         else if (kc <= 4) rc = run<4>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
-        else rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
+        else if (kc <= 8) rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
+        else rc = run<16>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
         if (rc) return rc;
     }
     return 0;
