@@ -220,12 +220,13 @@ int uni_cast_h2(const float* x, int ldx, void* out, int ldo, int M, int C, uni_s
  * w1 [4C][C], w2 [C][4C] (host, fp32; gamma [C] or NULL folded into the rows of w2) out as the f16x2 weight stream the kernel
  * consumes (uni_mlp_blob_bytes(C) bytes, host; copy it to the device) and returns the two accumulator factors.  a: f16x2 operand
  * rows (uni_cast_h2 / uni_dwconv7_ln output), b2 must already carry gamma; out may alias residual; out_h2 (optional) receives
- * an f16x2 copy of the result. */
+ * an f16x2 copy of the result.  layout 0: 4 waves x 32 rows per 128-row tile, one wave per SIMD (C = 96, 192, 256); layout 1: 8 waves x
+ * 16 rows, two waves per SIMD, v_mfma_f32_16x16x32_f16 (C = 192, 256; what the engine uses).  The blob is layout specific. */
 size_t uni_mlp_blob_bytes(int C);
-int uni_mlp_pack(const float* w1_host, const float* w2_host, const float* gamma_host, int C, void* blob_host, float* ws1_out,
-                 float* ws2_out);
+int uni_mlp_pack(const float* w1_host, const float* w2_host, const float* gamma_host, int C, int layout, void* blob_host,
+                 float* ws1_out, float* ws2_out);
 int uni_mlp_fused(const void* a_h2, int lda, const void* blob_dev, const float* b1, const float* b2, float ws1, float ws2,
-                  const float* residual, int ldr, float* out, int ldo, void* out_h2, int ldb, int M, int C, int dbg,
+                  const float* residual, int ldr, float* out, int ldo, void* out_h2, int ldb, int M, int C, int layout, int dbg,
                   uni_stream_t stream);
 int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, float* outF,
                   uint16_t* outB, uni_stream_t stream);

@@ -862,21 +862,22 @@ def test_convnext_block_with_folded_layernorm(L, shape, precision):
 # ------------------------------------------------------------------------------------------------
 # fused ConvNeXt MLP (mlp_fused.hip): pwconv1 -> GELU -> pwconv2 (gamma folded) -> + residual in one launch
 # ------------------------------------------------------------------------------------------------
-def mlp_pack(L, w1, w2, gamma):
+def mlp_pack(L, w1, w2, gamma, layout=0):
     C_ = w1.shape[1]
     nb = L.lib().uni_mlp_blob_bytes(C_)
     assert nb == 32 * C_ * C_
     blob = np.zeros(nb // 2, dtype=np.uint16)
     a, b = C.c_float(0), C.c_float(0)
     w1c, w2c, gc = (np.ascontiguousarray(t.float().numpy()) for t in (w1, w2, gamma))
-    L.check(L.lib().uni_mlp_pack(w1c.ctypes.data_as(C.c_void_p), w2c.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), C_,
+    L.check(L.lib().uni_mlp_pack(w1c.ctypes.data_as(C.c_void_p), w2c.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), C_, layout,
                                  blob.ctypes.data_as(C.c_void_p), C.byref(a), C.byref(b)), "mlp_pack")
     return torch.from_numpy(blob.view(np.int16)).cuda(), a.value, b.value
 
 
 @pytest.mark.parametrize("with_outb", [False, True])
-@pytest.mark.parametrize("C_,M", [(96, 1000), (192, 128), (192, 33000), (256, 4000), (256, 40001), (192, 1), (96, 70000)])
-def test_mlp_fused(L, C_, M, with_outb):
+@pytest.mark.parametrize("C_,M,layout", [(96, 1000, 0), (192, 128, 0), (192, 33000, 0), (256, 4000, 0), (256, 40001, 0), (192, 1, 0), (96, 70000, 0),
+                                         (192, 128, 1), (192, 33000, 1), (256, 4000, 1), (256, 40001, 1), (192, 1, 1), (192, 77777, 1)])
+def test_mlp_fused(L, C_, M, layout, with_outb):
     """convnext.py:47-54 after the LayerNorm: x + gamma * (W2 GELU(W1 a + b1) + b2), against torch fp64 on the f16x2-decoded
     operand; ragged M (rows past M are neither read nor written), several tiles per block (M > 128 * 256), in-place residual."""
     g = torch.Generator().manual_seed(C_ + M)
@@ -891,14 +892,14 @@ def test_mlp_fused(L, C_, M, with_outb):
     a_dec = h2_decode(A, M, C_)[0].cpu().double()
     hid = F.gelu(a_dec @ w1.double().t() + b1.double())
     ref = res.double() + gamma.double() * (hid @ w2.double().t() + b2.double())
-    blob, ws1, ws2 = mlp_pack(L, w1, w2, gamma)
+    blob, ws1, ws2 = mlp_pack(L, w1, w2, gamma, layout)
     pad = 64                                                 # guard rows behind the output: must stay untouched
     out = torch.full((M + pad, C_), 777.0, device="cuda")
     out[:M] = res.cuda()
     outb = torch.zeros((M + pad, C_), device="cuda", dtype=torch.int32) if with_outb else None
     b1d, b2d = b1.cuda(), (gamma * b2).cuda()
     L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1d), L.ptr(b2d), ws1, ws2, L.ptr(out), C_,
-                                  L.ptr(out), C_, L.ptr(outb), C_, M, C_, 0, L.stream_ptr()), "mlp_fused")
+                                  L.ptr(out), C_, L.ptr(outb), C_, M, C_, layout, 0, L.stream_ptr()), "mlp_fused")
     torch.cuda.synchronize()
     got = out[:M].cpu().double()
     scale = max(1.0, ref.abs().max().item())
@@ -928,7 +929,7 @@ def test_mlp_fused_matches_unfused_pair(L):
     fused = res.clone()
     b1d, b2d = b1.cuda(), (gamma * b2).cuda()
     L.check(L.lib().uni_mlp_fused(L.ptr(A), C_, L.ptr(blob), L.ptr(b1d), L.ptr(b2d), ws1, ws2, L.ptr(fused), C_,
-                                  L.ptr(fused), C_, None, 0, M, C_, 0, L.stream_ptr()), "mlp_fused")
+                                  L.ptr(fused), C_, None, 0, M, C_, 0, 0, L.stream_ptr()), "mlp_fused")
     W1p, s1 = pack_weight_h2(L, w1.reshape(4 * C_, C_, 1, 1))
     W2p, s2 = pack_weight_h2(L, (gamma[:, None] * w2).reshape(C_, 4 * C_, 1, 1))
     hid = torch.zeros((M, 4 * C_), device="cuda", dtype=torch.int32)

@@ -38,11 +38,13 @@ for name, Cc, m1 in SHAPES:
     b1, b2, gamma = torch.randn(4 * Cc, generator=g) * 0.1, torch.randn(Cc, generator=g) * 0.1, torch.rand(Cc, generator=g) + 0.5
     A = torch.empty((M, Cc), device="cuda", dtype=torch.int32)
     L.check(lib.uni_cast_h2(L.ptr(x), Cc, L.ptr(A), Cc, M, Cc, L.stream_ptr()), "cast")
-    blob = np.zeros(lib.uni_mlp_blob_bytes(Cc) // 2, dtype=np.uint16)
+    blobs = {}
     s1, s2 = C.c_float(0), C.c_float(0)
-    L.check(lib.uni_mlp_pack(w1.numpy().ctypes.data_as(C.c_void_p), w2.numpy().ctypes.data_as(C.c_void_p), gamma.numpy().ctypes.data_as(C.c_void_p),
-                             Cc, blob.ctypes.data_as(C.c_void_p), C.byref(s1), C.byref(s2)), "pack")
-    blob_d = torch.from_numpy(blob.view(np.int16)).cuda()
+    for lay in ((0, 1) if Cc in (192, 256) else (0,)):
+        blob = np.zeros(lib.uni_mlp_blob_bytes(Cc) // 2, dtype=np.uint16)
+        L.check(lib.uni_mlp_pack(w1.numpy().ctypes.data_as(C.c_void_p), w2.numpy().ctypes.data_as(C.c_void_p), gamma.numpy().ctypes.data_as(C.c_void_p),
+                                 Cc, lay, blob.ctypes.data_as(C.c_void_p), C.byref(s1), C.byref(s2)), "pack")
+        blobs[lay] = torch.from_numpy(blob.view(np.int16)).cuda()
     b1d, b2d = b1.cuda(), (gamma * b2).cuda()
     res = torch.randn(M, Cc, device="cuda")
     out = torch.empty_like(res)
@@ -67,16 +69,17 @@ for name, Cc, m1 in SHAPES:
     flop = 2.0 * 2.0 * M * 4 * Cc * Cc
     t_un = timeit(unfused)
     line = "%-16s M=%8d | unfused %7.1f us %6.1f TF |" % (name, M, t_un * 1e3, flop / t_un / 1e9)
-    for d in dbgs:
-        if d and Cc != 192:
-            continue
-        def fused():
-            L.check(lib.uni_mlp_fused(L.ptr(A), Cc, L.ptr(blob_d), L.ptr(b1d), L.ptr(b2d), s1.value, s2.value, L.ptr(res), Cc, L.ptr(out), Cc,
-                                      None, 0, M, Cc, d, L.stream_ptr()), "mlp_fused")
-        t = timeit(fused)
-        line += " fused[dbg%d] %7.1f us %6.1f TF |" % (d, t * 1e3, flop / t / 1e9)
-        if d == 0:
-            torch.cuda.synchronize()
-            err = (out - out2).abs().max().item()
-            line += " maxdiff %.2e |" % err
+    for lay in sorted(blobs):
+        for d in dbgs:
+            if d and Cc != 192:
+                continue
+            def fused():
+                L.check(lib.uni_mlp_fused(L.ptr(A), Cc, L.ptr(blobs[lay]), L.ptr(b1d), L.ptr(b2d), s1.value, s2.value, L.ptr(res), Cc, L.ptr(out), Cc,
+                                          None, 0, M, Cc, lay, d, L.stream_ptr()), "mlp_fused")
+            t = timeit(fused)
+            line += " L%d[dbg%d] %7.1f us %6.1f TF |" % (lay, d, t * 1e3, flop / t / 1e9)
+            if d == 0:
+                torch.cuda.synchronize()
+                err = (out - out2).abs().max().item()
+                line += " maxdiff %.2e |" % err
     print(line, flush=True)

@@ -63,8 +63,8 @@ PROTOS = {
                           c_f, c_i, c_f, c_i, c_i, C.c_void_p]),
     "uni_cast_h2": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, C.c_void_p]),
     "uni_mlp_blob_bytes": (C.c_size_t, [c_i]),
-    "uni_mlp_pack": (c_i, [C.c_void_p, C.c_void_p, C.c_void_p, c_i, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "uni_mlp_fused": (c_i, [c_f, c_i, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_i, C.c_void_p]),
+    "uni_mlp_pack": (c_i, [C.c_void_p, C.c_void_p, C.c_void_p, c_i, c_i, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "uni_mlp_fused": (c_i, [c_f, c_i, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     "uni_layernorm": (c_i, [c_f, c_i, c_f, c_f, C.c_float, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_dwconv7_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_f, C.c_void_p]),
     "uni_dwconv7_raw": (c_i, [c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),

@@ -271,15 +271,18 @@ int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int 
     API(launch_gemm(g, S(stream)));
 }
 size_t uni_mlp_blob_bytes(int C) { return mlp_fused_supported(C) ? mlp_blob_bytes(C) : 0; }
-int uni_mlp_pack(const float* w1, const float* w2, const float* gamma, int C, void* blob_out, float* ws1_out, float* ws2_out) {
+int uni_mlp_pack(const float* w1, const float* w2, const float* gamma, int C, int layout, void* blob_out, float* ws1_out, float* ws2_out) {
     UNI_REQUIRE(w1 && w2 && blob_out && ws1_out && ws2_out, "mlp_pack: NULL argument");
-    UNI_REQUIRE(mlp_fused_supported(C), "mlp_pack: C=%d unsupported (96, 192, 256)", C);
-    mlp_pack_host(w1, w2, gamma, C, reinterpret_cast<uint16_t*>(blob_out), ws1_out, ws2_out);
+    UNI_REQUIRE(layout == 0 || layout == 1, "mlp_pack: layout %d (0 = 32-row waves, 1 = 16-row waves)", layout);
+    UNI_REQUIRE(layout ? mlp_fused16_supported(C) : mlp_fused_supported(C), "mlp_pack: C=%d unsupported by layout %d (0: 96, 192, 256; 1: 192, 256)", C, layout);
+    if (layout) mlp_pack16_host(w1, w2, gamma, C, reinterpret_cast<uint16_t*>(blob_out), ws1_out, ws2_out);
+    else mlp_pack_host(w1, w2, gamma, C, reinterpret_cast<uint16_t*>(blob_out), ws1_out, ws2_out);
     return 0;
 }
 int uni_mlp_fused(const void* A, int lda, const void* blob, const float* b1, const float* b2, float ws1, float ws2, const float* residual,
-                  int ldr, float* out, int ldo, void* outB, int ldb, int M, int C, int dbg, uni_stream_t stream) {
+                  int ldr, float* out, int ldo, void* outB, int ldb, int M, int C, int layout, int dbg, uni_stream_t stream) {
     MlpArgs a;
+    a.layout = layout;
     a.A = A; a.lda = lda; a.blob = blob; a.b1 = b1; a.b2 = b2; a.ws1 = ws1; a.ws2 = ws2; a.res = residual; a.ldr = ldr;
     a.out = out; a.ldo = ldo; a.outB = outB; a.ldb = ldb; a.M = M; a.C = C; a.dbg = dbg;
     API(launch_mlp_fused(a, S(stream)));

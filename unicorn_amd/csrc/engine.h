@@ -7,6 +7,7 @@
 #include "../../include/unicorn_hip.h"
 #include "kernels.h"
 
+#define UNI_SLAB_BYTES ((size_t)32 << 20)   // budget of one split-K partial-tile slab (engine.hip choose_splitk); every concurrently running level owns one
 #define UNI_STATS_SLOTS 4096     // GroupNorm statistics slots per stage call: one per (GroupNorm, sample); backbone_fpn has 36 GNs, the mask head 31, B <= 64
 
 struct HostParam { std::vector<int64_t> shape; std::vector<float> data; };
@@ -14,7 +15,7 @@ struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad 
 struct PAffine { float* g = nullptr; float* b = nullptr; };
 struct PBlock { float* dw_w = nullptr; float* dw_b = nullptr; PAffine ln; PConv pw1, pw2; int C = 0;
                 float* pw1_colsum = nullptr; bool ln_folded = false;
-                void* mlp_blob = nullptr; float mlp_ws1 = 1.f, mlp_ws2 = 1.f; };   // mlp_blob: weight stream of the fused MLP kernel (mlp_fused.hip), f16x2 mode and C in {96, 192, 256}   // ln_folded: pw1 carries the LN gamma (weights) / beta (bias), colsum = row sums of the packed weights
+                void* mlp_blob = nullptr; float mlp_ws1 = 1.f, mlp_ws2 = 1.f; int mlp_layout = 0; };   // mlp_blob: weight stream of the fused MLP kernel (mlp_fused.hip), f16x2 mode and C in {96, 192, 256}   // ln_folded: pw1 carries the LN gamma (weights) / beta (bias), colsum = row sums of the packed weights
 struct PBaseConv { PConv conv; PAffine gn; int k = 1, stride = 1; };
 struct PCsp { PConv c12; PAffine gn12; PBaseConv m1[3], m2[3], c3; int cin = 0, cout = 0, h = 0; };
 

@@ -221,7 +221,11 @@ static PBlock pack_block(uni_ctx* c, const std::string& p, int C) {
     const float* w2 = host_param(c, p + "pwconv2.weight", (size_t)4 * C * C);
     if (c->b32 == FMT_H2 && mlp_fused_supported(C) && !b.ln_folded && !mlp_off && w1 && w2 && b.pw1.bias && b.pw2.bias) {
         std::vector<uint16_t> blob(mlp_blob_bytes(C) / 2);
-        mlp_pack_host(w1, w2, gamma, C, blob.data(), &b.mlp_ws1, &b.mlp_ws2);
+        // layout 1 (16-row waves, two per SIMD) where it exists; UNI_MLP_LAYOUT=0 forces the 32-row kernel (A/B switch)
+        static const char* lay_env = getenv("UNI_MLP_LAYOUT");
+        b.mlp_layout = (mlp_fused16_supported(C) && !(lay_env && lay_env[0] == '0')) ? 1 : 0;
+        if (b.mlp_layout) mlp_pack16_host(w1, w2, gamma, C, blob.data(), &b.mlp_ws1, &b.mlp_ws2);
+        else mlp_pack_host(w1, w2, gamma, C, blob.data(), &b.mlp_ws1, &b.mlp_ws2);
         b.mlp_blob = dev_upload<uint16_t>(c, blob.data(), blob.size());
     }
     return b;
@@ -373,7 +377,7 @@ int engine_finalize(uni_ctx* c) {
 // workspace
 // ------------------------------------------------------------------------------------------------
 int engine_reserve(uni_ctx* c, int B, int H, int W) {
-    const size_t need = (size_t)B * H * W * 3200 + ((size_t)96 << 20);   // >= head: 3 level slices (H*W/64*14336 B each) + casts + mask branch
+    const size_t need = (size_t)B * H * W * 3200 + ((size_t)96 << 20) + 4 * (UNI_SLAB_BYTES + 4096);   // >= head: 3 level slices (H*W/64*14336 B each) + casts + mask branch + split-K slabs
     if (need <= c->ws_cap) return 0;
     UNI_CHECK_HIP(hipSetDevice(c->device));
     UNI_CHECK_HIP(hipDeviceSynchronize());    // growing is rare; never happens inside a timed loop after warm-up
@@ -586,12 +590,13 @@ static int choose_splitk(const uni_ctx* c, const GemmArgs& g) {
     // tools/gemm_b1_bench.py on the single-frame shapes: 3x3 convolutions gain 25-50 % from ~400 blocks of >= 12 K steps (4000 x 384 x 3456:
     // 79 -> 60 us with 4 ranges, 1000 x 768 x 6912: 140 -> 69 us with 8); plain GEMMs only with very long K and few tiles (1000 x 1536 x 6144:
     // 107 -> 94 us); 1x1 convolutions and the stage-2 MLP (N >= 768, hundreds of 64 x 64 tiles) do not
+    int sk = 1;
     if (conv) {
         if (tiles > 128 || nk < 24) return 1;
-        int sk = (int)std::min<long>((400 + tiles / 2) / tiles, nk / 12);
-        return sk >= 2 ? std::min(sk, 8) : 1;
-    }
-    return (tiles <= 96 && nk >= 192) ? 4 : 1;
+        sk = std::min((int)std::min<long>((400 + tiles / 2) / tiles, nk / 12), 8);
+    } else if (tiles <= 96 && nk >= 192) sk = 4;
+    while (sk > 1 && (size_t)sk * g.M * g.N * sizeof(float) > UNI_SLAB_BYTES) --sk;      // the partial-tile slab has a fixed budget in the workspace plan
+    return sk >= 2 ? sk : 1;
 }
 
 // conv (no act) -> GroupNorm(G) -> act, written to `o`
@@ -647,7 +652,7 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
     if (b.mlp_blob && M >= 192 * 128 && !c->check_sat) {   // (check mode takes the two-launch path: the hidden tensor must exist to be scanned)
         MlpArgs m;
         m.A = t.p; m.lda = C; m.blob = b.mlp_blob; m.b1 = b.pw1.bias; m.b2 = b.pw2.bias; m.ws1 = b.mlp_ws1; m.ws2 = b.mlp_ws2;
-        m.res = x; m.ldr = C; m.out = x; m.ldo = C; m.outB = outB.p; m.ldb = C; m.M = M; m.C = C;
+        m.res = x; m.ldr = C; m.out = x; m.ldo = C; m.outB = outB.p; m.ldb = C; m.M = M; m.C = C; m.layout = b.mlp_layout;
         if (c->prof_on) c->prof_bytes += (double)M * C * (4.0 + 8.0 + (outB.p ? 4.0 : 0.0)) + (double)mlp_blob_bytes(C);
         const size_t before = c->recs.size();
         RUN(prof_run(c, PC_GEMM, 2.0 * 2.0 * M * 4.0 * C * C, s, [&] { return launch_mlp_fused(m, s); }));
@@ -904,7 +909,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     }
     const size_t lvl_base = (c->ws_off + 255) & ~(size_t)255;
     const size_t M0 = (size_t)B * HWk[0];
-    const size_t slice_bytes = ((M0 * 16384) + 65536 + 255) & ~(size_t)255;   // >= per-level footprint at level 0 (bf16 9.2 KB/pixel, fp32 15.4 KB/pixel)
+    const size_t slice_bytes = ((M0 * 16384) + 65536 + UNI_SLAB_BYTES + 4096 + 255) & ~(size_t)255;   // >= per-level footprint at level 0 (bf16 9.2 KB/pixel, fp32 15.4 KB/pixel) + one split-K slab
     const int row_start[3] = {0, HWk[0], HWk[0] + HWk[1]};
     for (int k = 0; k < 3; ++k) {
         const int M = B * HWk[k];                                // rows over the batch at this level

@@ -139,11 +139,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BKE == 16 ? 2 : 1)) void gemm_h2_ker
     if (p.splitk > 1) {                                // split-K: this block owns K steps [kt0, nk) of its tile
         const int per = (nk + p.splitk - 1) / p.splitk;
         kt0 = blockIdx.y * per;
-        nk = min(nk, kt0 + per);
-        if (kt0 >= nk) return;
+        nk = min(nk, kt0 + per);       // an empty range (kt0 >= nk) still stores its (zero) partial tile: the reduce kernel reads every slab
     }
     const int fr = lane & 31, fh = lane >> 5;
-    issue(kt0, 0);
+    if (kt0 < nk) issue(kt0, 0);
     for (int kt = kt0; kt < nk; ++kt) {
         const int buf = (kt - kt0) & 1;
         __syncthreads();                                   // K slice kt landed (vmcnt(0) + barrier); everyone is done with buf^1

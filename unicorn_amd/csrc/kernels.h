@@ -59,12 +59,15 @@ struct MlpArgs {
     float* out = nullptr; int ldo = 0;        // fp32 [M][C]
     void* outB = nullptr; int ldb = 0;        // optional f16x2 copy of the result
     int M = 0, C = 0;
+    int layout = 0;                           // 0: 32-row waves (4 per block, blob of mlp_pack_host); 1: 16-row waves (8 per block, mlp_pack16_host)
     int dbg = 0;                              // ablation switches (tools/mlp_bench.py, C = 192): 1 no DMA, 2 no MFMA, 16 no GELU arithmetic, 8 (any C) every block starts its weight stream at hidden block 0
 };
 int launch_mlp_fused(const MlpArgs& a, hipStream_t s);
 bool mlp_fused_supported(int C);
 size_t mlp_blob_bytes(int C);
 void mlp_pack_host(const float* w1, const float* w2, const float* gamma, int C, uint16_t* out, float* ws1, float* ws2);
+void mlp_pack16_host(const float* w1, const float* w2, const float* gamma, int C, uint16_t* out, float* ws1, float* ws2);
+bool mlp_fused16_supported(int C);
 
 // ---------------------------------------------------------------- norm.hip
 // Row LayerNorm over C (biased var, eps inside sqrt): fp32 [M][ldx] -> bf16 and/or fp32.
