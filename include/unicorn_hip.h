@@ -232,11 +232,12 @@ int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta
                   uint16_t* outB, uni_stream_t stream);
 int uni_dwconv7_ln(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta,
                    float eps, int H, int W, int C, uint16_t* out_bf16, uni_stream_t stream);
-/* LDS-tiled depthwise 7x7 (+bias) with the LayerNorm split off (convnext.py:43-47): raw conv output in operand format `fmt`
- * (0 bf16, 1 fp32, 2 f16x2) and per-pixel stats (B*H*W, 2) = (mean, rstd) of LN over C; the engine folds the LayerNorm into the
- * pwconv1 epilogue.  C % 32 == 0. */
-int uni_dwconv7_raw(const float* x_nhwc, const float* w49c, const float* bias, float eps, int B, int H, int W, int C, int fmt,
-                    void* out, float* stats, uni_stream_t stream);
+/* The engine's sampler of the ref <-> cur interaction (csrc/msda.hip msda_wave_kernel: one wave per (token, head), shuffle reductions):
+ * Unicorn's fixed geometry -- 8 heads x 32 channels, 2 levels = reference / current frame of identical (h, w), 4 points -- with
+ * MSDeformAttn.forward's softmax over the 8 logits and loc = ref + off / (W, H) fused in (ms_deform_attn.py:98-105,
+ * deformable_transformer.py:141-153).  value (B, 2 h w, 256) fp32; offaw (B * 2 h w, ldo >= 192): 128 sampling offsets
+ * (head, level, point, xy) then 64 attention logits (head, level, point) -> out (B * 2 h w, 256) fp32. */
+int uni_msda_tokens(const float* value, const float* offaw, int ldo, int B, int h, int w, float* out, uni_stream_t stream);
 int uni_groupnorm_act(const float* x, const double* stats, const float* gamma, const float* beta, float eps, int M,
                       int C, int G, int act, float* outF, uint16_t* outB, uni_stream_t stream);
 int uni_stem(const float* img, int H, int W, const float* w48c, const float* bias, const float* gamma,

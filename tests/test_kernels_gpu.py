@@ -324,6 +324,31 @@ def test_msda_random_vs_oracle(L):
     assert out0.shape == (1, 0, 256)
 
 
+@pytest.mark.parametrize("B,h,w", [(1, 50, 80), (2, 10, 13), (1, 7, 5)])
+def test_msda_wave_kernel_tokens(L, B, h, w):
+    """The engine's sampler (msda_wave_kernel: one wave per (token, head)) at kernel level against the oracle's statement of
+    MSDeformAttn.forward (ms_deform_attn.py:98-105: softmax over the 8 logits, loc = ref + off / (W, H)) + msda_core, including
+    offsets that leave the map (zero padding per corner, samples skipped outside (-1, W) x (-1, H))."""
+    g = torch.Generator().manual_seed(B * 100 + h)
+    hw = h * w
+    Lq = 2 * hw
+    value = torch.randn(B, Lq, 256, generator=g)
+    off = torch.randn(B, Lq, 8, 2, 4, 2, generator=g) * 6.0          # pixels: many samples land outside or on the border
+    off[:, :5] *= 30.0
+    logits = torch.randn(B, Lq, 8, 8, generator=g) * 2.0
+    offaw = torch.cat([off.reshape(B * Lq, 128), logits.reshape(B * Lq, 64)], 1).contiguous()
+    out = torch.empty(B * Lq, 256, device="cuda")
+    L.check(L.lib().uni_msda_tokens(L.ptr(value.cuda()), L.ptr(offaw.cuda()), 192, B, h, w, L.ptr(out), L.stream_ptr()), "uni_msda_tokens")
+    # reference points (deformable_transformer.py:141-153): ((j + 0.5) / W, (i + 0.5) / H), the same for both levels / frames
+    ii, jj = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    ref = torch.stack([(jj.reshape(-1) + 0.5) / w, (ii.reshape(-1) + 0.5) / h], -1).repeat(2, 1)       # (Lq, 2)
+    norm = torch.tensor([w, h], dtype=torch.float32)
+    loc = ref[None, :, None, None, None, :] + off / norm
+    attn = torch.softmax(logits, -1).view(B, Lq, 8, 2, 4)
+    want = uo.msda_core(value.view(B, Lq, 8, 32), [(h, w), (h, w)], loc, attn).reshape(B * Lq, 256)
+    assert torch.allclose(out.cpu(), want, rtol=1e-4, atol=2e-5), (out.cpu() - want).abs().max()
+
+
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("R,Q,K", [(1600, 1600, 1), (1000, 1300, 3), (4000, 2000, 5), (333, 257, 9), (1500, 1100, 16), (700, 900, 21)])
 def test_corr_softmax_pv(L, R, Q, K, prec):
@@ -568,7 +593,7 @@ def test_h2_cast_and_pack_formats(L):
     assert (wd - ref).abs().max() <= ref.abs().max() * 2.0 ** -21
 
 
-@pytest.mark.parametrize("cfg", [0, 42, 48, 44, 22, 12, 21, 11])
+@pytest.mark.parametrize("cfg", [0, 44, 22, 12, 21, 11])
 @pytest.mark.parametrize("case", [
     # (Hin, Win, Cin, N, KH, stride, pad, act, bias, res, stats_G)
     (20, 24, 96, 384, 1, 1, 0, 2, True, False, 0),        # pwconv1 + GELU, K = 96 (3 steps of 32)
@@ -701,7 +726,7 @@ def test_wrapper_error_paths_raise_unicorn_error(L):
         letterbox(torch.zeros(8, 8, 3, device="cuda", dtype=torch.float32), (32, 32))
 
 
-@pytest.mark.parametrize("cfg", [188, 144, 44, 48, 0])
+@pytest.mark.parametrize("cfg", [188, 44, 0])
 @pytest.mark.parametrize("case", [
     # (M, N, K, act, res, outF, outB): several tiles per persistent block
     (70001, 256, 64, 2, False, False, True),      # two K steps per tile, GELU, operand-format out, ragged M
@@ -824,39 +849,6 @@ def test_mots_mask_pipeline_device(L):
     assert np.array_equal(free.cpu().numpy(), ref_free)
     assert strs == [mo.mask_to_rle_string(m).decode("utf-8") for m in ref_free]
     assert mots_rle(m_dev[:0])[1] == [] and mots_threshold(score[:0].cuda(), scale, h, w).shape == (0, h, w)
-
-
-# ------------------------------------------------------------------------------------------------
-# LDS-tiled raw depthwise conv + LayerNorm folded into the consumer GEMM (dwconv.hip, GemmArgs::rowstat)
-# ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
-@pytest.mark.parametrize("shape", [(1, 192, 40, 56), (2, 96, 25, 40), (1, 256, 13, 21), (1, 768, 50, 80)])
-def test_convnext_block_with_folded_layernorm(L, shape, precision):
-    """One ConvNeXt block through the engine (raw dwconv7 + per-pixel statistics -> pwconv1 with the LayerNorm folded into its
-    epilogue -> GELU -> pwconv2 -> gamma -> +residual) against torch fp64, via a 1-stage model is overkill: the block is
-    exercised through uni_backbone-free entry points below (kernel + GEMM), and end to end by tests/test_model_gpu.py."""
-    import ctypes as C
-    B, Cc, H, W = shape
-    g = torch.Generator().manual_seed(Cc + H)
-    x = torch.randn(B, Cc, H, W, generator=g) * 2.0 + 0.3
-    dw = torch.randn(Cc, 1, 7, 7, generator=g) * 0.1
-    db = torch.randn(Cc, generator=g) * 0.1
-    ref = F.conv2d(x.double(), dw.double(), db.double(), padding=3, groups=Cc).permute(0, 2, 3, 1).reshape(-1, Cc)
-    mean, var = ref.mean(1), ref.var(1, unbiased=False)
-    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
-    w49 = dw.reshape(Cc, 49).t().contiguous().cuda()
-    fmt = {"bf16": 0, "f16x2": 2}[precision]
-    M = B * H * W
-    out = torch.zeros((M, Cc), device="cuda", dtype=torch.int32 if fmt == 2 else torch.bfloat16)
-    stats = torch.zeros((M, 2), device="cuda")
-    L.check(L.lib().uni_dwconv7_raw(L.ptr(xn), L.ptr(w49), L.ptr(db.cuda()), 1e-6, B, H, W, Cc, fmt, L.ptr(out), L.ptr(stats), L.stream_ptr()), "dwconv7_raw")
-    torch.cuda.synchronize()
-    got = h2_decode(out, M, Cc)[0].cpu().double() if fmt == 2 else out.float().cpu().double()
-    tol = 2e-6 if fmt == 2 else 1e-2
-    assert (got - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
-    st = stats.cpu().double()
-    assert (st[:, 0] - mean).abs().max() < 2e-6 * max(1.0, mean.abs().max().item())
-    assert ((st[:, 1] - 1 / torch.sqrt(var + 1e-6)).abs() / (1 / torch.sqrt(var + 1e-6))).max() < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------

@@ -589,17 +589,16 @@ def test_raw_outputs_decode_in_inference_false():
         mm.head(fpn, pri, mode="mot")
 
 
-def test_layernorm_folded_into_pwconv1_optional_path():
-    """UNI_DW_RAW=1 (read when the weights are packed): LDS-tiled raw depthwise conv + per-pixel statistics, LayerNorm folded into the
-    pwconv1 epilogue (csrc/dwconv.hip, GemmArgs::rowstat).  Off by default (not faster, DESIGN.md §4) but kept exact: the golden
-    parity tests must pass with it, for both 16-bit operand formats."""
+@pytest.mark.parametrize("env", [{"UNI_MLP_LAYOUT": "0"}, {"UNI_NO_MLP_FUSED": "1", "UNI_NO_SPLITK": "1"}], ids=["mlp32", "unfused_nosplit"])
+def test_engine_ab_switches_keep_parity(env):
+    """The launch-plan switches of the engine (read when the weights are packed / per call) select kernels that are no longer the
+    default: the 32-row fused MLP (UNI_MLP_LAYOUT=0), the two-launch MLP and unsplit single-frame convolutions.  The large SOT parity
+    test must pass with each of them."""
     import subprocess
     import sys
-    env = dict(os.environ, UNI_DW_RAW="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "test_tiny_320_vs_reference_golden and unicorn_track_tiny_mask and not fp32"], env=env, capture_output=True, text=True,
-                       cwd=ROOT, timeout=900)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_large_sot_800x1280_vs_oracle and f16x2"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
 def test_omni_mot_frame_batched_equals_per_frame_and_oracle():

@@ -311,13 +311,12 @@ int uni_dwconv7_ln(const float* x, const float* w49c, const float* bias, const f
     d.out = reinterpret_cast<bf16*>(out);
     API(launch_dwconv7_ln(d, S(stream)));
 }
-int uni_dwconv7_raw(const float* x, const float* w49c, const float* bias, float eps, int B, int H, int W, int C, int fmt, void* out,
-                    float* stats, uni_stream_t stream) {
-    UNI_REQUIRE(x && w49c && bias && out && stats && (fmt == FMT_BF16 || fmt == FMT_H2 || fmt == FMT_F32), "dwconv7_raw: bad argument");
-    DwRawArgs d;
-    d.x = x; d.w = w49c; d.bias = bias; d.eps = eps; d.B = B; d.H = H; d.W = W; d.C = C; d.fmt = fmt;
-    d.out = reinterpret_cast<bf16*>(out); d.stats = stats;
-    API(launch_dwconv7_raw(d, S(stream)));
+int uni_msda_tokens(const float* value, const float* offaw, int ldo, int B, int h, int w, float* out, uni_stream_t stream) {
+    UNI_REQUIRE(value && offaw && out && B > 0 && h > 0 && w > 0 && ldo >= 192, "msda_tokens: bad argument");
+    MsdaFusedArgs m;
+    m.value = value; m.offaw = offaw; m.ldo = ldo; m.h = h; m.w = w; m.B = B;
+    m.out = reinterpret_cast<bf16*>(out); m.b32 = FMT_F32;
+    API(launch_msda_fused(m, S(stream)));
 }
 int uni_groupnorm_act(const float* x, const double* stats, const float* gamma, const float* beta, float eps, int M, int C, int G,
                       int act, float* outF, uint16_t* outB, uni_stream_t stream) {

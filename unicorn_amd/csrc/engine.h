@@ -14,7 +14,6 @@ struct HostParam { std::vector<int64_t> shape; std::vector<float> data; };
 struct PConv { bf16* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, KH = 1, KW = 1, Cin = 0, b32 = 0; float wscale = 1.f; };
 struct PAffine { float* g = nullptr; float* b = nullptr; };
 struct PBlock { float* dw_w = nullptr; float* dw_b = nullptr; PAffine ln; PConv pw1, pw2; int C = 0;
-                float* pw1_colsum = nullptr; bool ln_folded = false;
                 void* mlp_blob = nullptr; float mlp_ws1 = 1.f, mlp_ws2 = 1.f; int mlp_layout = 0; };   // mlp_blob: weight stream of the fused MLP kernel (mlp_fused.hip), f16x2 mode and C in {96, 192, 256}   // ln_folded: pw1 carries the LN gamma (weights) / beta (bias), colsum = row sums of the packed weights
 struct PBaseConv { PConv conv; PAffine gn; int k = 1, stride = 1; };
 struct PCsp { PConv c12; PAffine gn12; PBaseConv m1[3], m2[3], c3; int cin = 0, cout = 0, h = 0; };
@@ -29,7 +28,6 @@ struct uni_ctx {
     std::vector<float> zeros;
     std::vector<void*> dev_allocs;
     bool finalized = false, failed = false;
-    std::vector<double>* pack_rowsum = nullptr;   // when set, pack_convs stores the row sums of the ROUNDED packed weights (unscaled) here
     int b32 = 0;   // precision mode = operand format (ActFmt): 0 = bf16 MFMA operands, 1 = exact fp32 (v_mfma_f32_32x32x2_f32), 2 = split f16 ("f16x2", fp32-equivalent)
     // ConvNeXt
     float* stem_w = nullptr; float* stem_b = nullptr; PAffine stem_ln;

@@ -105,14 +105,6 @@ static PConv pack_convs(uni_ctx* c, const std::vector<ConvSrc>& srcs, int Cin, i
         n0 += s.N;
     }
     p.b32 = c->b32;
-    if (c->pack_rowsum) {          // row sums of the weights as the MFMA will see them (bf16-rounded; the f16x2 branch overwrites them below)
-        c->pack_rowsum->assign(N, 0.0);
-        for (int n = 0; n < N; ++n) {
-            double acc = 0.0;
-            for (int k = 0; k < p.Kpad; ++k) { uint32_t u = (uint32_t)packed[(size_t)n * p.Kpad + k] << 16; float f; memcpy(&f, &u, 4); acc += f; }
-            (*c->pack_rowsum)[n] = acc;
-        }
-    }
     if (c->b32 == FMT_H2) {   // split-f16 mode: [Npad][Kpad] x (hi, lo) f16 in 32-byte groups of 8 k, one power-of-two scale per packed tensor
         float mx = 0.f;
         for (auto& s : srcs) {
@@ -132,13 +124,6 @@ static PConv pack_convs(uni_ctx* c, const std::vector<ConvSrc>& srcs, int Cin, i
             if (w) pack_weight_h2_host(w, s.N, Cin, KH, KW, s.row_scale, scale, ph.data() + (size_t)r0 * p.Kpad * 2, s.N, p.Kpad);
             r0 += s.N;
         }
-        if (c->pack_rowsum)
-            for (int n = 0; n < N; ++n) {
-                double acc = 0.0;
-                const uint16_t* o = ph.data() + (size_t)n * p.Kpad * 2;
-                for (int k = 0; k < p.Kpad; ++k) acc += (double)f16_to_f32_host(o[(k >> 3) * 16 + (k & 7)]) + (double)f16_to_f32_host(o[(k >> 3) * 16 + 8 + (k & 7)]);
-                (*c->pack_rowsum)[n] = acc * (double)p.wscale;
-            }
         p.W = reinterpret_cast<bf16*>(dev_upload<uint16_t>(c, ph.data(), ph.size()));
     } else if (c->b32 == FMT_F32) {   // exact-fp32 mode: same [Npad][Kpad] (ky,kx,c) layout, fp32 elements
         std::vector<float> pf((size_t)Npad * p.Kpad, 0.f);
@@ -180,46 +165,14 @@ static PBlock pack_block(uni_ctx* c, const std::string& p, int C) {
     b.dw_w = dev_upload<float>(c, t.data(), t.size());
     b.dw_b = up_vec(c, p + "dwconv.bias", C);
     b.ln = up_affine(c, p + "norm.", C);
-    const float* lg = host_param(c, p + "norm.weight", C);
-    const float* lb = host_param(c, p + "norm.bias", C);
     const float* w1 = host_param(c, p + "pwconv1.weight", (size_t)4 * C * C);
-    const float* b1 = host_param(c, p + "pwconv1.bias", (size_t)4 * C);
-    // Opt-in (UNI_DW_RAW=1 at load time): measured on MI355X the LDS-tiled raw kernel is NOT faster than the fused register/L1
-    // kernels of norm.hip (stage-2 maps 291 vs 207 us per 16 frames; only the 200x320 maps win, 572-839 vs 727 us): with one
-    // block per CU (124 KB of double-buffered halo tiles) its 7 waves cannot overlap LDS reads (3.3k clk per chunk) with the FMAs
-    // (3.1k clk per SIMD), see DESIGN.md §4.  The fold itself is exact (tests/test_model_gpu.py runs the golden parity with it).
-    static const bool fold_on = getenv("UNI_DW_RAW") != nullptr;
-    if (c->b32 != FMT_F32 && C % 32 == 0 && lg && lb && w1 && b1 && fold_on) {
-        // LayerNorm folded into pwconv1 (dwconv.hip): W1' = W1 diag(gamma), b1' = b1 + W1 beta, colsum_n = sum_k of the ROUNDED packed
-        // W1'[n][k] (so that mean * colsum cancels exactly what the MFMA accumulated), applied as rstd * (acc - mean * colsum) + b1'
-        const int N = 4 * C;
-        std::vector<float> wf((size_t)N * C), bf(N);
-        for (int n = 0; n < N; ++n) {
-            double acc = b1[n];
-            for (int k = 0; k < C; ++k) { wf[(size_t)n * C + k] = w1[(size_t)n * C + k] * lg[k]; acc += (double)w1[(size_t)n * C + k] * lb[k]; }
-            bf[n] = (float)acc;
-        }
-        c->host["__fold." + p + "w"] = HostParam{{N, C}, wf};
-        c->host["__fold." + p + "b"] = HostParam{{N}, bf};
-        std::vector<double> rs;
-        c->pack_rowsum = &rs;
-        b.pw1 = pack_conv(c, "__fold." + p + "w", "__fold." + p + "b", N, C);
-        c->pack_rowsum = nullptr;
-        std::vector<float> cs(N);
-        for (int n = 0; n < N; ++n) cs[n] = (float)rs[n];
-        b.pw1_colsum = dev_upload<float>(c, cs.data(), cs.size());
-        b.ln_folded = true;
-        c->host.erase("__fold." + p + "w");
-        c->host.erase("__fold." + p + "b");
-    } else {
-        b.pw1 = pack_conv(c, p + "pwconv1.weight", p + "pwconv1.bias", 4 * C, C);
-    }
+    b.pw1 = pack_conv(c, p + "pwconv1.weight", p + "pwconv1.bias", 4 * C, C);
     const float* gamma = host_param(c, p + "gamma", C);   // layer scale folded into pwconv2 (convnext.py:50-51)
     b.pw2 = pack_conv(c, p + "pwconv2.weight", p + "pwconv2.bias", C, 4 * C, 1, 1, gamma);
     // fused pwconv1 -> GELU -> pwconv2 -> + residual (mlp_fused.hip) for the narrow blocks of the f16x2 mode; UNI_NO_MLP_FUSED = A/B switch
     static const bool mlp_off = getenv("UNI_NO_MLP_FUSED") != nullptr;
     const float* w2 = host_param(c, p + "pwconv2.weight", (size_t)4 * C * C);
-    if (c->b32 == FMT_H2 && mlp_fused_supported(C) && !b.ln_folded && !mlp_off && w1 && w2 && b.pw1.bias && b.pw2.bias) {
+    if (c->b32 == FMT_H2 && mlp_fused_supported(C) && !mlp_off && w1 && w2 && b.pw1.bias && b.pw2.bias) {
         std::vector<uint16_t> blob(mlp_blob_bytes(C) / 2);
         // layout 1 (16-row waves, two per SIMD) where it exists; UNI_MLP_LAYOUT=0 forces the 32-row kernel (A/B switch)
         static const char* lay_env = getenv("UNI_MLP_LAYOUT");
@@ -629,17 +582,8 @@ static int run_baseconv(uni_ctx* c, const PBaseConv& b, ActPtr A, int lda, int H
 // ConvNeXt block on the fp32 residual stream x [H*W][C] (in place); t/hid are caller-provided scratch
 static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr t, ActPtr hid, ActPtr outB, hipStream_t s) {
     const int C = b.C, M = H * W * c->nb;
-    const bool fold = b.ln_folded;        // decided when the weights were packed (UNI_DW_RAW)
-    float* rowstat = nullptr;
     const size_t mark = c->ws_off;
-    if (fold) {   // LDS-tiled raw depthwise conv + per-pixel (mean, rstd); the LayerNorm is applied in the pwconv1 epilogue
-        rowstat = wsalloc<float>(c, (size_t)M * 2);
-        DwRawArgs d;
-        d.x = x; d.w = b.dw_w; d.bias = b.dw_b; d.eps = 1e-6f; d.H = H; d.W = W; d.C = C; d.B = c->nb; d.out = t; d.stats = rowstat; d.fmt = c->b32;
-        const size_t before = c->recs.size();
-        RUN(prof_run(c, PC_DWLN, (double)M * C * (4.0 + act_elem_bytes(c->b32)) + 49.0 * C * 4, s, [&] { return launch_dwconv7_raw(d, s); }));
-        if (c->recs.size() > before) { ProfRec& r = c->recs.back(); r.M = M; r.N = C; r.K = W; }
-    } else {
+    {
         DwLnArgs d;
         d.x = x; d.w = b.dw_w; d.bias = b.dw_b; d.gamma = b.ln.g; d.beta = b.ln.b; d.eps = 1e-6f;
         d.H = H; d.W = W; d.C = C; d.B = c->nb; d.out = t;
@@ -661,7 +605,6 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
         return 0;
     }
     GemmArgs g1 = conv_args(b.pw1, t, C, M, 1, 1, 0);
-    g1.rowstat = rowstat; g1.colsum = fold ? b.pw1_colsum : nullptr;
     g1.act = ACT_GELU; g1.outB = hid; g1.ldb = 4 * C;
     RUN(p_gemm(c, g1, s));
     GemmArgs g2 = conv_args(b.pw2, hid, 4 * C, M, 1, 1, 0);
@@ -669,7 +612,7 @@ static int run_block(uni_ctx* c, const PBlock& b, float* x, int H, int W, ActPtr
     const int sk2 = outB.p ? 1 : choose_splitk(c, g2);
     if (sk2 > 1) { g2.splitk = sk2; g2.slab = wsalloc<float>(c, (size_t)sk2 * M * C); }
     RUN(p_gemm(c, g2, s));
-    c->ws_off = mark;        // rowstat is dead once pwconv1 is enqueued (in-order stream)
+    c->ws_off = mark;
     return 0;
 }
 

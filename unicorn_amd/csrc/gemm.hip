@@ -343,8 +343,6 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     UNI_REQUIRE(a.M % a.Mper == 0 && a.M / a.Mper < 128, "gemm: M=%d is not a multiple of Mper=%d", a.M, a.Mper);
     UNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     UNI_REQUIRE(((uintptr_t)a.A & 15) == 0, "gemm: A must be 16-byte aligned");
-    if (a.rowstat) UNI_REQUIRE(a.colsum && !a.stats && a.b32 != FMT_F32 && ((uintptr_t)a.rowstat & 7) == 0 && ((uintptr_t)a.colsum & 15) == 0,
-                               "gemm: rowstat needs colsum, no GroupNorm statistics, a 16-bit operand format");
     if (a.b32 == FMT_H2) return launch_gemm_h2(a, s);
     UNI_REQUIRE(a.K % (a.b32 == FMT_F32 ? 4 : 8) == 0 && a.Kpad % 64 == 0 && a.Kpad >= a.K, "gemm: K=%d Kpad=%d", a.K, a.Kpad);
     UNI_REQUIRE(a.lda % (a.b32 == FMT_F32 ? 4 : 8) == 0 && ((uintptr_t)a.A & 15) == 0, "gemm: lda=%d / A must be 16-byte aligned", a.lda);
@@ -403,7 +401,6 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     // plain GEMMs that would take the 256x256 tile go to the persistent variant (gemm_p44.hip): -5..-20 % on the MLP shapes
     if (cfg == 44 && a.force_cfg % 1000 == 0 && gemm_p44_supported(a) && !no_p44) cfg = 144;
     if (cfg == 144 && !gemm_p44_supported(a)) cfg = 44;
-    if (a.rowstat) UNI_REQUIRE(a.epi, "gemm: rowstat needs the vector-aligned (staged) epilogue");
     if (cfg == 144) return launch_gemm_p44(a, s);
     if (!a.epi && (cfg == 44 || cfg == 42 || cfg == 24)) cfg = 22;
 #define GOS(WM, WN, TM, TN, BK, NS) return conv ? launch_cfg<WM, WN, TM, TN, BK, true, NS>(a, s) : launch_cfg<WM, WN, TM, TN, BK, false, NS>(a, s)

@@ -30,12 +30,6 @@ __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&ac
         // phase A: bias + activation in the MFMA layout, float4 chunks to LDS [row fr][chunk ^ (fr & 7)].  The activation
         // kind is dispatched ONCE per slab (uniform branch) so the 32-element loops are branch-free; the column window
         // (act_col0) is a select.
-        float rs_mean = 0.f, rs_rstd = 1.f;           // LayerNorm of the A row folded in: v = rstd * (acc - mean * colsum)
-        if (p.rowstat) {
-            const int row = m0 + wm * 32 * TM + i * 32 + fr;
-            const float2 st2 = *reinterpret_cast<const float2*>(p.rowstat + 2 * (size_t)(row < p.M ? row : p.M - 1));
-            rs_mean = st2.x; rs_rstd = st2.y;
-        }
         auto phase_a = [&](auto act_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -44,11 +38,6 @@ __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&ac
                 for (int g = 0; g < 4; ++g) {
                     const int col = nw0 + j * 32 + 8 * g + 4 * fh;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    if (p.rowstat) {
-                        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.colsum + (col < p.N ? col : 0));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rs_rstd * fmaf(-rs_mean, cs[e], v[e]);
-                    }
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
                     if (ACT != ACT_NONE) {
 #pragma unroll

@@ -323,7 +323,7 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     const double util44 = (double)a.N / (cdiv(a.N, 256) * 256.0);
     int cfg = a.force_cfg % 1000;
     if (a.splitk > 1) {
-        UNI_REQUIRE(a.outF && a.slab && !a.outB && a.act == ACT_NONE && !a.rowstat && !a.out_hw, "gemm(h2): split-K needs fp32 output + a slab, no activation / operand-format output");
+        UNI_REQUIRE(a.outF && a.slab && !a.outB && a.act == ACT_NONE && !a.out_hw, "gemm(h2): split-K needs fp32 output + a slab, no activation / operand-format output");
         UNI_REQUIRE(a.splitk <= 64 && a.N % 4 == 0 && a.ldf % 4 == 0 && (!a.res || a.ldr % 4 == 0) && a.Mper > 0 && a.M % a.Mper == 0 && a.epi,
                     "gemm(h2): splitk=%d N=%d ldf=%d Mper=%d", a.splitk, a.N, a.ldf, a.Mper);
         if (a.stats) UNI_REQUIRE(a.cpg > 0 && a.N % a.cpg == 0 && a.N / a.cpg <= 32, "gemm(h2): split-K statistics cpg=%d", a.cpg);
@@ -338,7 +338,7 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
             if (!no_q && a.N > 64 && a.K % 32 == 0 && nks % a.splitk == 0 && nks / a.splitk >= 2 && gemm_h2q_supported(g)) return launch_gemm_h2q(a, s);
             UNI_REQUIRE(cfg != 188, "gemm(h2): ping-pong split-K does not support this problem");
         }
-        if (cfg == 0 || cfg == 44 || cfg == 48 || cfg == 42 || cfg == 188 || cfg == 144) cfg = (a.N <= 64) ? 21 : 22;
+        if (cfg == 0 || cfg == 44 || cfg == 188) cfg = (a.N <= 64) ? 21 : 22;
     }
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
@@ -350,21 +350,15 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
         else if (conv) cfg = b12 >= 400 ? 12 : 11;
         else cfg = b21 >= 400 ? 21 : 11;
     }
-    if (a.rowstat) UNI_REQUIRE(a.epi, "gemm(h2): rowstat needs the vector-aligned (staged) epilogue");
-    if (!a.epi && (cfg == 44 || cfg == 48 || cfg == 42)) cfg = 22;
-    // plain GEMMs that take the 256 x 256 tile go to the persistent variants: the ping-pong kernel (gemm_h2q.hip, 188), or
-    // gemm_h2p.hip (144) for what that one does not cover (LayerNorm fold, a single K step); UNI_NO_H2Q / UNI_NO_H2P = A/B switches
-    if (cfg == 44 && a.force_cfg % 1000 == 0 && !getenv("UNI_NO_H2P")) {
+    if (!a.epi && cfg == 44) cfg = 22;
+    // problems that take the 256 x 256 tile go to the persistent ping-pong kernel (gemm_h2q.hip, cfg 188) where it covers them; UNI_NO_H2Q = A/B switch
+    if (cfg == 44 && a.force_cfg % 1000 == 0) {
         static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;
         if (!no_q && gemm_h2q_supported(a)) cfg = 188;
-        else if (gemm_h2p_supported(a)) cfg = 144;
     }
     if (cfg == 188) return gemm_h2q_supported(a) ? launch_gemm_h2q(a, s) : (uni_set_error("gemm(h2): ping-pong variant does not support this problem"), -1);
-    if (cfg == 144) return gemm_h2p_supported(a) ? launch_gemm_h2p(a, s) : (uni_set_error("gemm(h2): persistent variant does not support this problem"), -1);
 #define GOH(WM, WN, TM, TN) return conv ? launch_h2_cfg<WM, WN, TM, TN, true>(a, s) : launch_h2_cfg<WM, WN, TM, TN, false>(a, s)
     switch (cfg) {
-        case 42: return conv ? launch_h2_cfg<2, 2, 4, 2, true, 16>(a, s) : launch_h2_cfg<2, 2, 4, 2, false, 16>(a, s);   // 256 x 128, 4 waves of 128 x 64, 16-k steps (48 KiB LDS): TWO blocks per CU, one block's epilogue runs under the other's MFMAs
-        case 48: GOH(2, 4, 4, 2);     // 256 x 256, 8 waves (2 x 4) of 128 x 64 wave tiles, 128 KiB LDS, fragment prefetch
         case 44: GOH(4, 4, 2, 2);     // 256 x 256, 16 waves, 128 KiB LDS
         case 22: GOH(2, 2, 2, 2);     // 128 x 128
         case 12: GOH(2, 2, 1, 2);     // 64 x 128

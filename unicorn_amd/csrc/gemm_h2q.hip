@@ -1,4 +1,4 @@
-// PING-PONG variant of the persistent 256 x 256 split-f16 ("f16x2") GEMM (gemm_h2p.hip) for the plain contractions: ConvNeXt
+// PING-PONG persistent 256 x 256 split-f16 ("f16x2") GEMM for the plain contractions: ConvNeXt
 // pointwise MLPs and transformer Linears (convnext.py:41-54 pwconv1 / pwconv2; deformable_transformer.py:122-131).
 //
 // 8 waves = 2 wave groups (M halves) x 4 (N quarters), a wave owns 128 x 64 of the tile (128 accumulator registers).  A K step
@@ -17,7 +17,7 @@
 // last read of the slot it overwrites (reads are retired with
 // lgkmcnt(0) before the barrier that ends their phase); after the wait in phase 4 every half-tile of step S+1 has landed for all
 // waves once both groups have passed their next barrier, i.e. before anybody's phase 1 of step S+1.
-// Epilogue = gemm_h2p.hip's (bias, activation, residual, fp32 / operand-format outputs through a per-wave 4-KiB
+// Epilogue (bias, activation, residual, fp32 / operand-format outputs through a per-wave 4-KiB
 // staging block), staged in its own 32 KiB so the DMA of the next tile keeps flying.
 #include "kernels.h"
 #include "gemm_epi.h"
@@ -454,7 +454,7 @@ bool gemm_h2q_supported(const GemmArgs& a) {
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
     if (a.b32 != FMT_H2 && a.b32 != FMT_BF16) return false;
     const int ks = a.b32 == FMT_H2 ? 32 : 64, eb = a.b32 == FMT_H2 ? 4 : 2;
-    if (!a.epi || a.K % ks != 0 || a.K < 2 * ks || a.rowstat || a.act_col0 != 0) return false;
+    if (!a.epi || a.K % ks != 0 || a.K < 2 * ks || a.act_col0 != 0) return false;
     if (!conv && !a.stats) {
         if (a.b32 != FMT_H2) return gemm_p44_supported(a);
         return a.out_hw == 0 && (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_GELU) && (a.outF || a.outB) && (a.outF || !a.res);   // (bias optional)

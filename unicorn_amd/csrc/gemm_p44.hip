@@ -178,12 +178,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_p44_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float rs_mean = 0.f, rs_rstd = 1.f;       // LayerNorm of the A row folded in (GemmArgs::rowstat): rstd * (acc - mean * colsum) + bias
-            if (p.rowstat) {
-                const int row = rb0 + i * 32 + fr;
-                const float2 st2 = *reinterpret_cast<const float2*>(p.rowstat + 2 * (size_t)(row < p.M ? row : p.M - 1));
-                rs_mean = st2.x; rs_rstd = st2.y;
-            }
             if (!OUTF) {
                 // bf16 [32 rows][64 cols] (128-B rows); 16-B chunks XOR-swizzled with (row >> 1) & 7
 #pragma unroll
@@ -193,14 +187,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_p44_kernel(GemmArgs p) {
                         const int col = nw0 + j * 32 + 8 * g + 4 * fh;
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
                         float v[4];
-                        if (p.rowstat) {
-                            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.colsum + (col < p.N ? col : 0));
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(rs_rstd, fmaf(-rs_mean, cs[e], acc[i][j][4 * g + e]), b4[e]));
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(acc[i][j][4 * g + e] + b4[e]);
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(acc[i][j][4 * g + e] + b4[e]);
                         bf16x2 w0 = {(bf16)v[0], (bf16)v[1]}, w1 = {(bf16)v[2], (bf16)v[3]};
                         u32x2 o2 = {__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w1)};
                         const int chunk = (j * 4 + g) ^ ((fr >> 1) & 7);             // 16-B chunk holding cols 8g..8g+7 of block j
@@ -227,14 +215,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_p44_kernel(GemmArgs p) {
                         const int col = nw0 + j * 32 + 8 * g + 4 * fh;
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + (col < p.N ? col : 0));
                         f32x4 v;
-                        if (p.rowstat) {
-                            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.colsum + (col < p.N ? col : 0));
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(fmaf(rs_rstd, fmaf(-rs_mean, cs[e], acc[i][j][4 * g + e]), b4[e]));
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(acc[i][j][4 * g + e] + b4[e]);
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(acc[i][j][4 * g + e] + b4[e]);
                         *reinterpret_cast<f32x4*>(st + fr * 128 + (((2 * g + fh) ^ (fr & 7)) << 4)) = v;
                     }
                     wave_fence();

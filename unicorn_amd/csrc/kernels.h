@@ -21,9 +21,6 @@ struct GemmArgs {
     int force_cfg = 0;                        // 0 = heuristic, else 22 / 12 / 21 / 11
     int b32 = 0;                              // operand format (ActFmt): FMT_BF16, FMT_F32 (A, W, outB fp32; v_mfma_f32_32x32x2_f32) or FMT_H2 (split f16, gemm_h2.hip)
     float wscale = 1.f;                       // FMT_H2: the packed weights carry a power-of-two scale; the accumulator is multiplied by wscale
-    // LayerNorm of the A rows folded into the epilogue: v = rstd[m] * (acc - mean[m] * colsum[n]) (+ bias): rowstat [M][2] = (mean, rstd)
-    // from dwconv7_raw, colsum [N] = row sums of the packed weights (which carry the LN gamma), bias = b + W beta
-    const float* rowstat = nullptr; const float* colsum = nullptr;
     // FMT_H2, single-frame problems (few tiles): splitk > 1 cuts the K loop into `splitk` ranges (gridDim.y); every range stores its partial
     // tile into slab [splitk][M][N] fp32 and a reduce kernel (launched by launch_gemm_h2) sums the ranges and applies bias / residual /
     // GroupNorm sums -> outF.  No activation, no operand-format output in this mode.
@@ -40,8 +37,6 @@ void pack_weight_h2_host(const float* w, int N, int Cin, int KH, int KW, const f
                          int Npad, int Kpad);
 int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persistent 256x256 tiles (bf16), next tile prefetched before the drain
 bool gemm_p44_supported(const GemmArgs& a);
-int launch_gemm_h2p(const GemmArgs& a, hipStream_t s);    // gemm_h2p.hip: the same for the split-f16 format
-bool gemm_h2p_supported(const GemmArgs& a);
 GemmArgs gemm_splitk_partial_args(const GemmArgs& a);    // the launch that fills the slab: fp32 partial tiles only (no bias / residual / statistics / remap)
 int launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 int launch_gemm_h2q(const GemmArgs& a, hipStream_t s);    // gemm_h2q.hip: persistent 256x256, two wave groups ping-pong MFMA / LDS phases, counted-vmcnt DMA stream
@@ -110,21 +105,6 @@ struct DwLnArgs {
     int b32 = 0;
 };
 int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s);
-
-// dwconv.hip: LDS-tiled depthwise 7x7 (+bias) WITHOUT the LayerNorm: raw conv output in the operand format + per-pixel
-// (mean, rstd) of LN over C; the consumer GEMM applies them (GemmArgs::rowstat / colsum)
-struct DwRawArgs {
-    const float* x = nullptr;                 // [B][H][W][C] fp32
-    const float* w = nullptr;                 // [49][C]
-    const float* bias = nullptr;
-    float eps = 1e-6f;
-    int H = 0, W = 0, C = 0, B = 1;
-    bf16* out = nullptr;                      // [B*H*W][C] operand format `fmt`
-    float* stats = nullptr;                   // [B*H*W][2] = (mean, rstd)
-    int fmt = 0;
-    int dbg = 0;                              // ablation switches (UNI_DW_DBG): 1 no DMA after chunk 0, 2 one tap row only, 4 no output stores, 8 the 8-px / 4-wave variant
-};
-int launch_dwconv7_raw(const DwRawArgs& a, hipStream_t s);
 
 // stem: conv4x4/s4 (3->C) + bias + LN_cf: NCHW fp32 image -> fp32 NHWC
 struct StemArgs {

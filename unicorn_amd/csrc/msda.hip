@@ -68,43 +68,9 @@ int launch_msda(const float* value, const int64_t* shapes, const int64_t* lsi, c
     return 0;
 }
 
-// Engine variant for Unicorn's fixed geometry (8 heads x 32 ch, 2 levels = ref / cur frame of identical
-// (h,w), 4 points): fuses ms_deform_attn.py:98-105 (softmax over the 8 logits, loc = ref + off/(W,H)) and
-// deformable_transformer.py:141-153 (reference points) into the sampler; emits bf16 for output_proj.
-__global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs p) {
-    const int hw = p.h * p.w, Lq = 2 * hw;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)Lq * 256 * p.B) return;
-    const int d = idx & 31, m = (idx >> 5) & 7;
-    const int qg = (int)(idx >> 8);                              // token over [B][2 frames][hw]
-    const int sb = qg / Lq, q = qg - sb * Lq;
-    const float* row = p.offaw + (size_t)qg * p.ldo;
-    const float* off = row + m * 16;
-    const float* lg = row + 128 + m * 8;
-    float w8[8], mx = -3.0e38f, sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { w8[i] = lg[i]; mx = fmaxf(mx, w8[i]); }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { w8[i] = __expf(w8[i] - mx); sum += w8[i]; }
-    const float inv = 1.f / sum;
-    const int pos = q % hw, i0 = pos / p.w, j0 = pos - i0 * p.w;
-    const float refx = (j0 + 0.5f) / p.w, refy = (i0 + 0.5f) / p.h;
-    float acc = 0.f;
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        const float* vb = p.value + ((size_t)sb * Lq + (size_t)l * hw) * 256 + m * 32 + d;
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const float lx = refx + off[(l * 4 + pt) * 2] / p.w;
-            const float ly = refy + off[(l * 4 + pt) * 2 + 1] / p.h;
-            const float x = lx * p.w - 0.5f, y = ly * p.h - 0.5f;
-            if (y > -1 && x > -1 && y < p.h && x < p.w)
-                acc += (w8[l * 4 + pt] * inv) * msda_bilinear(vb, p.h, p.w, 256, y, x);
-        }
-    }
-    act_store1(p.out, (size_t)idx, acc, p.b32);
-}
-
+// Engine variant for Unicorn's fixed geometry (8 heads x 32 ch, 2 levels = ref / cur frame of identical (h,w), 4 points): fuses
+// ms_deform_attn.py:98-105 (softmax over the 8 logits, loc = ref + off/(W,H)) and deformable_transformer.py:141-153 (reference
+// points) into the sampler; emits the operand format of output_proj.
 // CDNA4 shape of the same op: ONE WAVE per (token, head).  The 64 lanes are 8 groups x 8 lanes: group g owns sampling point g
 // (level g >> 2, point g & 3), lane j of a group owns channels 4j..4j+3 of the 32-channel head row, so a corner fetch of a
 // group is one 128-byte row as 8 x float4.  The softmax over the 8 logits and the final sum over the 8 points are butterfly
@@ -156,12 +122,6 @@ __global__ __launch_bounds__(256) void msda_wave_kernel(MsdaFusedArgs p) {
 }
 
 int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s) {
-    static const bool lane_per_channel = getenv("UNI_MSDA_V1") != nullptr;      // A/B switch: the round-1 kernel
-    if (lane_per_channel) {
-        const long total = (long)2 * a.h * a.w * 256 * a.B;
-        hipLaunchKernelGGL(msda_fused_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-        return 0;
-    }
     const long tasks = (long)2 * a.h * a.w * 8 * a.B;
     hipLaunchKernelGGL(msda_wave_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, s, a);
     return 0;
