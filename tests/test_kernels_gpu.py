@@ -338,7 +338,9 @@ def test_msda_wave_kernel_tokens(L, B, h, w):
     logits = torch.randn(B, Lq, 8, 8, generator=g) * 2.0
     offaw = torch.cat([off.reshape(B * Lq, 128), logits.reshape(B * Lq, 64)], 1).contiguous()
     out = torch.empty(B * Lq, 256, device="cuda")
-    L.check(L.lib().uni_msda_tokens(L.ptr(value.cuda()), L.ptr(offaw.cuda()), 192, B, h, w, L.ptr(out), L.stream_ptr()), "uni_msda_tokens")
+    vd, od = value.cuda(), offaw.cuda()                              # (kept alive across the asynchronous launch)
+    L.check(L.lib().uni_msda_tokens(L.ptr(vd), L.ptr(od), 192, B, h, w, L.ptr(out), L.stream_ptr()), "uni_msda_tokens")
+    torch.cuda.synchronize()
     # reference points (deformable_transformer.py:141-153): ((j + 0.5) / W, (i + 0.5) / H), the same for both levels / frames
     ii, jj = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
     ref = torch.stack([(jj.reshape(-1) + 0.5) / w, (ii.reshape(-1) + 0.5) / h], -1).repeat(2, 1)       # (Lq, 2)
@@ -976,11 +978,12 @@ def test_gemm_h2_splitk(L, case):
     A = cast_h2(L, x[0].permute(1, 2, 0).reshape(M, Cin).contiguous().cuda())
     Wp, ws = pack_weight_h2(L, w)
     res0 = torch.randn(M, N, generator=g).cuda()
+    bias_d = bias.cuda()
     outs, stats = [], []
     for split in (1, sk):
         out = res0.clone() if use_res else torch.zeros((M, N), device="cuda")
         st = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
-        L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), ws, M, N, Hin, Win, Cin, k, k, 1, pad, L.ptr(bias.cuda()) if True else None, 0,
+        L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), ws, M, N, Hin, Win, Cin, k, k, 1, pad, L.ptr(bias_d), 0,
                                     L.ptr(out) if use_res else None, N, L.ptr(out), N, None, 0, L.ptr(st), N // G if G else 0,
                                     cfg + (100000 * split if split > 1 else 0), L.stream_ptr()), "gemm_h2")
         torch.cuda.synchronize()

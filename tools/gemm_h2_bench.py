@@ -1,6 +1,6 @@
 """Micro-benchmark of the split-f16 ("f16x2") GEMM kernel (gemm_h2.hip) over the dominant shapes of the 800x1280 large model
 at GEMM_SCALE frames per launch (default 16 = the bench step).  TF = fp32-EQUIVALENT (algorithmic) TFLOP/s; the MFMA pipe
-issues 3x that.      python tools/gemm_h2_bench.py [cfg ...]      (cfg 0 = heuristic, 48 / 44 / 22 / ...)"""
+issues 3x that.      python tools/gemm_h2_bench.py [cfg ...]      (cfg 0 = heuristic, 188 / 44 / 22 / ...)"""
 import ctypes as C
 import os
 import sys
@@ -25,7 +25,7 @@ SHAPES = [
 if os.environ.get("ONLY"):
     SHAPES = [s_ for s_ in SHAPES if os.environ["ONLY"] in s_[0]]
 ZERO = bool(os.environ.get("ZERO"))
-cfgs = [int(a) for a in sys.argv[1:]] or [0, 48, 44, 22]
+cfgs = [int(a) for a in sys.argv[1:]] or [0, 188, 44, 22]
 print("%-18s %8s %6s %6s | " % ("shape", "M", "N", "K") + " ".join("%12s" % ("cfg%d" % c) for c in cfgs))
 for name, Hin, Win, Cin, N, k, act, use_res, use_F, use_B in SHAPES:
     B = SCALE

@@ -29,8 +29,9 @@ for tag, d in (("fetch", sys.argv[1]), ("write", sys.argv[2])):
         if cname not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         name = kname.split("(")[0].replace("void ", "")
-        # GEMM classes: all bf16 instantiations incl. the persistent gemm_bf16_p44; all split-f16 ones incl. gemm_h2p
-        cls = "gemm_bf16_kernel" if "gemm_bf16" in name else ("gemm_h2_kernel" if "gemm_h2" in name else name[:40])
+        # GEMM classes as bench.py's roofline leg counts them: all bf16 instantiations incl. the persistent gemm_bf16_p44; all split-f16
+        # ones incl. the ping-pong kernel and the fused MLP (one launch = both GEMMs of a ConvNeXt block)
+        cls = "gemm_bf16_kernel" if "gemm_bf16" in name else ("gemm_h2_kernel" if ("gemm_h2" in name or "mlp_fused" in name) else name[:40])
         acc[cls][0] += val * 1024.0 * (2.0 if tag == "fetch" else 1.0)
         acc[cls][1] += 1
     for k, (b, n) in acc.items():
