@@ -83,6 +83,12 @@ def lib():
     """Load libunicorn_hip.so (built by __graft_entry__.build() / unicorn_amd/csrc/build.sh).  No fallback."""
     global _lib
     if _lib is None:
+        # torch first: PyTorch-ROCm brings its own libamdhip64; loading ours before it puts two HIP runtimes into the process and the
+        # second one sees no device ("no HIP device 0 (count 0)")
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise UnicornHipError(
                 "libunicorn_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -25,6 +25,9 @@ def gather_result_rows(rows, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return _sort(rows)
     world = dist.get_world_size(group)
+    out_dev = rows.device
+    if dist.get_backend(group) != "nccl":          # gloo (CPU tests, or a GPU run forced onto gloo): collectives on host copies
+        rows = rows.cpu()
     dev = rows.device
     n = torch.tensor([rows.shape[0]], device=dev, dtype=torch.int64)
     counts = [torch.zeros_like(n) for _ in range(world)]
@@ -35,7 +38,7 @@ def gather_result_rows(rows, group=None):
     pad[:rows.shape[0]] = rows
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
-    return _sort(torch.cat([o[:c] for o, c in zip(out, counts)], 0))
+    return _sort(torch.cat([o[:c] for o, c in zip(out, counts)], 0)).to(out_dev)
 
 
 def gather_byte_strings(items, group=None):
