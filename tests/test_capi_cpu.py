@@ -87,3 +87,67 @@ def test_fails_loudly_without_gpu():
         corr_softmax_pv(torch.zeros(128, 4), torch.zeros(128, 4), torch.zeros(1, 4))
     with pytest.raises(_lib.UnicornHipError):
         m(imgs=torch.zeros(1, 3, 32, 32), mode="backbone")
+
+
+def _f16_pairs(blob_u16):
+    return blob_u16.view(np.float16).astype(np.float64)
+
+
+@pytest.mark.parametrize("C_,layout", [(96, 0), (192, 0), (256, 0), (192, 1), (256, 1)])
+def test_mlp_pack_layouts_match_numpy_restatement(C_, layout):
+    """Host packer of the fused ConvNeXt MLP (csrc/mlp_fused.hip): the weight stream is 2 * NH pieces of 128 C bytes, blob position 2 i =
+    W1 slab of hidden block i, 2 i + 1 = W2 slab of hidden block i - 1 (cyclic), every piece in the LDS image of its kernel layout, values
+    split into hi + lo f16 halves of w * 2^k.  Restated here from the kernel's fragment addressing and decoded back to the weights."""
+    from unicorn_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.RandomState(C_ + layout)
+    w1 = (rng.randn(4 * C_, C_) * 0.05).astype(np.float32)
+    w2 = (rng.randn(C_, 4 * C_) * 0.05).astype(np.float32)
+    gamma = (rng.rand(C_) + 0.5).astype(np.float32)
+    nb = lib.uni_mlp_blob_bytes(C_)
+    assert nb == 32 * C_ * C_
+    blob = np.zeros(nb // 2, dtype=np.uint16)
+    a, b = C.c_float(0), C.c_float(0)
+    assert lib.uni_mlp_pack(w1.ctypes.data_as(C.c_void_p), w2.ctypes.data_as(C.c_void_p), gamma.ctypes.data_as(C.c_void_p), C_, layout,
+                            blob.ctypes.data_as(C.c_void_p), C.byref(a), C.byref(b)) == 0
+    s1, s2 = 1.0 / a.value, 1.0 / b.value
+    assert np.log2(s1) == round(np.log2(s1)) and np.log2(s2) == round(np.log2(s2))          # power-of-two scales
+    assert 2 ** 14 <= np.abs(w1).max() * s1 < 2 ** 15
+    v = _f16_pairs(blob)
+    NH, PBh = C_ // 8, 64 * C_                                   # hidden blocks, f16 values per piece
+    r1, r2 = np.zeros_like(w1, dtype=np.float64), np.zeros_like(w2, dtype=np.float64)
+    for i in range(NH):
+        p1 = v[(2 * i) * PBh:(2 * i + 1) * PBh]
+        p2 = v[(2 * i + 1) * PBh:(2 * i + 2) * PBh]
+        h2 = (i - 1) % NH
+        if layout == 0:      # 32-row waves: W1 [slice 16 k][row 32][chunk ^ ((r >> 2) & 3)], W2 [col block 32][row 32][chunk ^ ((r >> 1) & 7)]
+            q = p1.reshape(C_ // 16, 32, 4, 8)
+            for r in range(32):
+                for pc in range(4):
+                    c = pc ^ ((r >> 2) & 3)
+                    fh, hl = c >> 1, c & 1
+                    for s in range(C_ // 16):
+                        r1[32 * i + r, 16 * s + 8 * fh:16 * s + 8 * fh + 8] += q[s, r, pc]       # hi + lo
+            q = p2.reshape(C_ // 32, 32, 8, 8)
+            perm = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]                # k position -> hidden unit inside 16
+            for j in range(C_ // 32):
+                for r in range(32):
+                    for pc in range(8):
+                        c = pc ^ ((r >> 1) & 7)
+                        s, fh = c >> 2, (c >> 1) & 1
+                        for e in range(8):
+                            r2[32 * j + r, 32 * h2 + 16 * s + perm[8 * fh + e]] += q[j, r, pc, e]
+        else:                # 16-row waves: [..][kg 4][hi, lo][row 16] x 8 values
+            q = p1.reshape(2, C_ // 32, 4, 2, 16, 8)
+            for ub in range(2):
+                for s in range(C_ // 32):
+                    for kg in range(4):
+                        r1[32 * i + 16 * ub:32 * i + 16 * ub + 16, 32 * s + 8 * kg:32 * s + 8 * kg + 8] = q[ub, s, kg, 0] + q[ub, s, kg, 1]
+            q = p2.reshape(C_ // 16, 4, 2, 16, 8)
+            for j in range(C_ // 16):
+                for kg in range(4):
+                    for e in range(8):
+                        u = 4 * kg + e if e < 4 else 16 + 4 * kg + e - 4
+                        r2[16 * j:16 * j + 16, 32 * h2 + u] = q[j, kg, 0, :, e] + q[j, kg, 1, :, e]
+    assert np.abs(r1 / s1 - w1).max() <= np.abs(w1).max() * 2.0 ** -21
+    assert np.abs(r2 / s2 - gamma[:, None] * w2).max() <= np.abs(gamma[:, None] * w2).max() * 2.0 ** -21
