@@ -730,10 +730,7 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
     const int hw = h * w, C2 = c->cfg.dims[2];
     const size_t L = (size_t)2 * hw * B;                    // tokens over the batch
     ActPtr fb = actalloc(c, L * C2);
-    for (int b = 0; b < B; ++b) {
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_ref + (size_t)b * hw * C2, C2, fb + (size_t)(2 * b) * hw * C2, C2, hw, C2, s, c->b32); }));
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(feat_cur + (size_t)b * hw * C2, C2, fb + (size_t)(2 * b + 1) * hw * C2, C2, hw, C2, s, c->b32); }));
-    }
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_pair(feat_ref, feat_cur, fb, hw, C2, B, s, c->b32); }));     // tokens [B][ref | cur][hw]
     float* src = wsalloc<float>(c, L * 256);
     ActPtr srcb = actalloc(c, L * 256);
     {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5) per frame = 2B "samples" of hw rows
@@ -761,12 +758,11 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
     ActPtr hid = actalloc(c, L * 1024);
     { GemmArgs g = conv_args(c->lin1, srcb, 256, (int)L, 1, 1, 0); g.act = ACT_RELU; g.outB = hid; g.ldb = 1024; RUN(p_gemm(c, g, s)); }
     { GemmArgs g = conv_args(c->lin2, hid, 1024, (int)L, 1, 1, 0); g.res = src; g.ldr = 256; g.outF = y; g.ldf = 256; RUN(p_gemm(c, g, s)); }
-    for (int b = 0; b < B; ++b)
-        for (int l = 0; l < 2; ++l) {
-            LnArgs ln; ln.x = y + (size_t)(2 * b + l) * hw * 256; ln.ldx = 256; ln.gamma = c->norm2.g; ln.beta = c->norm2.b; ln.eps = 1e-5f;
-            ln.M = hw; ln.C = 256; ln.outF = (l ? out_cur : out_ref) + (size_t)b * hw * 256; ln.ldf = 256;
-            RUN(p_ln(c, ln, s));
-        }
+    {   // src = norm2(src + ffn): tokens [B][2][hw] back to the two frame maps, one launch
+        LnArgs ln; ln.x = y; ln.ldx = 256; ln.gamma = c->norm2.g; ln.beta = c->norm2.b; ln.eps = 1e-5f;
+        ln.M = (int)L; ln.C = 256; ln.outF = out_ref; ln.outF2 = out_cur; ln.pair_hw = hw; ln.ldf = 256;
+        RUN(p_ln(c, ln, s));
+    }
     return 0;
 }
 

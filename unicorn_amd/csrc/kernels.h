@@ -76,6 +76,9 @@ struct LnArgs {
     // channel c -> pixel (2y+dy, 2x+dx), channel c/4 of a (2h,2w,C/4) map
     int ps_h = 0, ps_w = 0;
     int b32 = 0;                              // outB holds fp32 instead of bf16
+    // optional fp32 row remap of the interaction stage: rows are tokens [B][2 frames][pair_hw]; frame 0 rows go to outF, frame 1 rows to
+    // outF2, both as [B][pair_hw] maps (one launch instead of 2 B)
+    float* outF2 = nullptr; int pair_hw = 0;
 };
 int launch_layernorm(const LnArgs& a, hipStream_t s);
 
@@ -138,6 +141,8 @@ size_t corr_workspace_bytes(int R, int Q, int K);
 
 // ---------------------------------------------------------------- misc.hip
 int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32 = 0);
+// x0 / x1 [B][hw][C] fp32 (two frames) -> out [B][2][hw][C] in the operand format (the token layout of the interaction stage), one launch
+int launch_cast_pair(const float* x0, const float* x1, bf16* out, int hw, int C, int B, hipStream_t s, int b32);
 int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32 = 0, int B = 1);
 int launch_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, hipStream_t s);
 int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s, int B = 1);

@@ -22,6 +22,28 @@ int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, 
     return 0;
 }
 
+__global__ void cast_pair_kernel(const float* x0, const float* x1, bf16* out, int hw, int C8, int B, int b32) {
+    const long total = (long)2 * B * hw * C8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / C8;                       // token over [B][2][hw]
+        const int c = (int)(e - row * C8) * 8;
+        const long t = row / hw;
+        const int pix = (int)(row - t * hw);
+        const float* src = ((t & 1) ? x1 : x0) + (((t >> 1) * hw + pix) * (long)C8 * 8) + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        act_store8(out, (size_t)row * C8 * 8 + c, v, b32);
+    }
+}
+int launch_cast_pair(const float* x0, const float* x1, bf16* out, int hw, int C, int B, hipStream_t s, int b32) {
+    UNI_REQUIRE(C % 8 == 0 && hw > 0 && B > 0, "cast_pair: C=%d hw=%d B=%d", C, hw, B);
+    const long total = (long)2 * B * hw * (C / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(cast_pair_kernel, dim3(grid), dim3(256), 0, s, x0, x1, out, hw, C / 8, B, b32);
+    return 0;
+}
+
 // PixelShuffle(2) + cast: fp32 NHWC (h,w,C) -> bf16 NHWC (2h,2w,C/4); in channel c*4+dy*2+dx -> out (2y+dy,2x+dx,c)
 __global__ void pixel_shuffle_kernel(const float* x, bf16* out, int h, int w, int C, int b32, int B) {
     const int Co = C >> 2;

@@ -48,7 +48,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if (p.outF) *reinterpret_cast<float4*>(p.outF + (size_t)row * p.ldf + idx * 4) = o;
+            if (p.outF) {
+                if (p.pair_hw) {     // tokens [B][2][hw] -> frame maps [B][hw]
+                    const int t = row / p.pair_hw, pix = row - t * p.pair_hw;
+                    float* dst = (t & 1) ? p.outF2 : p.outF;
+                    *reinterpret_cast<float4*>(dst + ((size_t)(t >> 1) * p.pair_hw + pix) * p.ldf + idx * 4) = o;
+                } else {
+                    *reinterpret_cast<float4*>(p.outF + (size_t)row * p.ldf + idx * 4) = o;
+                }
+            }
             if (p.outB) {
                 if (p.ps_h) {   // PixelShuffle(2) scatter: channel c=4*idx+{0..3} -> (dy,dx) = (j>>1, j&1), out ch idx
                     int y = row / p.ps_w, xx = row - y * p.ps_w;
