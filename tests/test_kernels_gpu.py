@@ -710,7 +710,7 @@ def test_gemm_h2_large_and_subnormal_lo(L):
     mag = x.abs().double() @ w.abs().double().cuda().t()
     A = cast_h2(L, x)
     Wp, wscale = pack_weight_h2(L, w.reshape(N, K, 1, 1))
-    for cfg in (0, 42, 48, 44, 22):
+    for cfg in (0, 44, 22, 322, 323):
         outF = torch.full((M, N), float("nan"), device="cuda")
         L.check(L.lib().uni_gemm_h2(L.ptr(A), K, L.ptr(Wp), wscale, M, N, M, 1, K, 1, 1, 1, 0, None, 0, None, N,
                                     L.ptr(outF), N, None, N, None, 0, cfg, L.stream_ptr()), "gemm_h2")
@@ -952,6 +952,63 @@ def test_mots_threshold_matches_reference_crop_shape():
     assert (got.cpu().bool() != ref).float().mean() < 1e-5            # thresholding an fp32 interpolation: ties at round-off only
     full = mots_threshold(om.cuda(), scale, img_h, img_w, 0.3, crop=False)
     assert tuple(full.shape) == (3, img_h, img_w) and not full[:, :, img_w - 1:].any()
+
+
+@pytest.mark.parametrize("cfg", [322, 323, 332, 331])
+@pytest.mark.parametrize("case", [
+    # (Hin, Win, Cin, N, k, stride, pad, act, res, stats_G, outB, splitk)
+    (4000, 1, 3072, 768, 1, 1, 0, 0, True, 0, False, 1),      # stage-2 pwconv2 of one frame + in-place residual (256 tiles of 128 x 96)
+    (1003, 1, 768, 3072, 1, 1, 0, 2, False, 0, True, 1),      # pwconv1 + GELU -> operand-format out, ragged M
+    (50, 80, 384, 384, 3, 1, 1, 0, False, 16, False, 1),      # FPN / head 3x3, zero padding through the range check, GroupNorm sums
+    (26, 34, 192, 192, 3, 2, 1, 0, False, 16, False, 1),      # 3x3 stride 2, ragged M
+    (20, 20, 96, 200, 2, 2, 0, 1, False, 0, True, 1),         # 2x2 / s2 downsample, ReLU, N = 200 (ragged in every tile width)
+    (130, 1, 64, 96, 1, 1, 0, 0, False, 0, False, 1),         # K = 64: two slices, fewer than the ring holds
+    (25, 40, 256, 256, 3, 1, 1, 0, False, 16, False, 4),      # split-K: K ranges of 18 slices, statistics from the reduce kernel
+    (1000, 1, 3072, 768, 1, 1, 0, 0, True, 0, False, 5),      # split-K with unequal ranges (96 slices / 5) + in-place residual
+])
+def test_gemm_h2_deep(L, cfg, case):
+    """gemm_h2d.hip (4-wave tiles with an NST-deep counted-vmcnt DMA ring, descriptor addressing) against fp64 on the unrounded
+    operands AND bit for bit against gemm_h2_kernel (cfg 22: same MFMA order per accumulator, so fp32 results must be identical);
+    three launches must reproduce themselves (a DMA / fragment-read race shows up as run-to-run differences)."""
+    Hin, Win, Cin, N, k, stride, pad, act, use_res, G, use_B, sk = case
+    g = torch.Generator().manual_seed(Hin * 3 + N + k)
+    x = (torch.randn(1, Cin, Hin, Win, generator=g) * 2.0).cuda()
+    w = torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    ref = F.conv2d(x.double(), w.double().cuda(), bias.double(), stride=stride, padding=pad)
+    mag = F.conv2d(x.abs().double(), w.abs().double().cuda(), None, stride=stride, padding=pad)
+    Hout, Wout = ref.shape[2:]
+    M = Hout * Wout
+    raw = ref.permute(0, 2, 3, 1).reshape(M, N)
+    mag = mag.permute(0, 2, 3, 1).reshape(M, N)
+    res0 = torch.randn(M, N, generator=g).cuda() if use_res else None
+    exp = ACTS[act](raw) + (res0.double() if use_res else 0)
+    A = cast_h2(L, x.permute(0, 2, 3, 1).reshape(Hin * Win, Cin).contiguous())
+    Wp, wscale = pack_weight_h2(L, w)
+    tol = mag * 2.0 ** -20 + 1e-6
+
+    def run(c):
+        outF = res0.clone() if use_res else (None if use_B else torch.full((M, N), float("nan"), device="cuda"))
+        outB = torch.zeros((M, N), device="cuda", dtype=torch.int32) if use_B else None
+        stats = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
+        L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), wscale, M, N, Hin, Win, Cin, k, k, stride, pad, L.ptr(bias), act,
+                                    L.ptr(outF) if use_res else None, N, L.ptr(outF), N, L.ptr(outB), N, L.ptr(stats), (N // G) if G else 0,
+                                    c + (100000 * sk if sk > 1 else 0), L.stream_ptr()), "gemm_h2")
+        torch.cuda.synchronize()
+        return (outB if use_B else outF), stats
+
+    outs = [run(cfg) for _ in range(3)]
+    got = h2_decode(outs[0][0], M, N)[0].double() if use_B else outs[0][0].double()
+    assert torch.isfinite(got).all()
+    assert ((got - exp).abs() <= tol * 1.2 + (exp.abs() * 2.0 ** -21 if use_B else 0)).all(), ((got - exp).abs() / tol).max()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+    base, bstats = run(22)
+    assert torch.equal(outs[0][0], base)
+    if G:
+        grp = raw.reshape(M, G, N // G)
+        s_ref = torch.stack([grp.sum((0, 2)), (grp ** 2).sum((0, 2))], 1)
+        s_got = outs[0][1][:2 * G].reshape(G, 2)
+        assert torch.allclose(s_got, s_ref, rtol=2e-5, atol=5e-2), (s_got - s_ref).abs().max()
 
 
 @pytest.mark.parametrize("case", [

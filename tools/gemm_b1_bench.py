@@ -18,10 +18,15 @@ SHAPES = [
     ("s3.pw2 1000x1536x6144", 1000, 1, 6144, 1536, 1, 0, 1, 0), ("s3.pw1 1000x6144x1536 gelu", 1000, 1, 1536, 6144, 1, 2, 0, 1),
     ("s1.pw2 16000x384x1536", 16000, 1, 1536, 384, 1, 0, 1, 0), ("s1.pw1 16000x1536x384 gelu", 16000, 1, 384, 1536, 1, 2, 0, 1),
     ("fpn1x1 4000x768x1536", 4000, 1, 1536, 768, 1, 0, 0, 0), ("fpn1x1 1000x1536x3072", 1000, 1, 3072, 1536, 1, 0, 0, 0),
+    ("fpn3x3 16000x192x1728", 100, 160, 192, 192, 3, 0, 0, 0), ("head3x3 16000x128x2304", 100, 160, 256, 128, 3, 0, 0, 0),
+    ("1x1 4000x384x384", 4000, 1, 384, 384, 1, 0, 0, 0), ("1x1 16000x256x1024", 16000, 1, 1024, 256, 1, 0, 0, 0),
+    ("1x1 16000x1024x256", 16000, 1, 256, 1024, 1, 0, 0, 0), ("1x1 4000x768x768", 4000, 1, 768, 768, 1, 0, 0, 0),
+    ("1x1 16000x192x192", 16000, 1, 192, 192, 1, 0, 0, 0), ("1x1 4000x256x1024", 4000, 1, 1024, 256, 1, 0, 0, 0),
 ]
-CFGS = [0, 188, 22, 11]
-SPLITS = [1, 2, 3, 4, 6, 8]
-print("%-28s | " % "shape" + " ".join("%9s" % ("c%d/s%d" % (c, sk)) for c in CFGS for sk in (SPLITS if c in (188, 22) else [1])))
+CFGS = [0, 188, 22, 11, 322, 323, 332, 331]
+SPLITS = [1, 2, 3, 4]
+SPLIT_CFGS = (188, 22, 323, 331)
+print("%-28s | " % "shape" + " ".join("%9s" % ("c%d/s%d" % (c, sk)) for c in CFGS for sk in (SPLITS if c in SPLIT_CFGS else [1])))
 for name, Hin, Win, Cin, N, k, act, use_res, use_B in SHAPES:
     pad = (k - 1) // 2
     M = Hin * Win
@@ -38,7 +43,7 @@ for name, Hin, Win, Cin, N, k, act, use_res, use_B in SHAPES:
     outB = torch.empty((M, N), device="cuda", dtype=torch.int32) if use_B else None
     cells = []
     for cfg in CFGS:
-        for sk in (SPLITS if cfg in (188, 22) else [1]):
+        for sk in (SPLITS if cfg in SPLIT_CFGS else [1]):
             if sk > 1 and (act or use_B):
                 cells.append("        -")
                 continue

@@ -544,7 +544,13 @@ static int choose_splitk(const uni_ctx* c, const GemmArgs& g) {
     // 79 -> 60 us with 4 ranges, 1000 x 768 x 6912: 140 -> 69 us with 8); plain GEMMs only with very long K and few tiles (1000 x 1536 x 6144:
     // 107 -> 94 us); 1x1 convolutions and the stage-2 MLP (N >= 768, hundreds of 64 x 64 tiles) do not
     int sk = 1;
-    if (conv) {
+    if (gemm_h2d_choice(g)) {
+        // deep-pipeline 64 x 64 tiles (3 blocks per CU): only problems with < ~200 of them still leave CUs empty (1000 x 256 x 2304: 26 -> 22 us,
+        // 1000 x 768 x 6912: 73 -> 58 us with 3 ranges); everything larger is faster unsplit (no slab round trip)
+        const long t64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+        if (t64 > 200 || nk < 36) return 1;
+        sk = 3;
+    } else if (conv) {
         if (tiles > 128 || nk < 24) return 1;
         sk = std::min((int)std::min<long>((400 + tiles / 2) / tiles, nk / 12), 8);
     } else if (tiles <= 96 && nk >= 192) sk = 4;

@@ -65,14 +65,17 @@ __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&ac
         const int rbase = m0 + wm * 32 * TM + i * 32;
         if (!p.outF && !p.res) {
             constexpr int Q = CW / 8, RPI = 64 / Q;        // 8-channel (16-B bf16) pieces per row, rows per instruction
+            constexpr bool EXACT = 64 % Q == 0;            // TN = 3 (96-wide wave tiles): 60 of the 64 lanes carry a piece, 7 instructions
             const int q = lane % Q, rr = lane / Q;
             const int col = nw0 + 8 * q;
 #pragma unroll
-            for (int t = 0; t < 32 / RPI; ++t) {
-                const int r = t * RPI + rr, row = rbase + r;
+            for (int t = 0; t < (32 + RPI - 1) / RPI; ++t) {
+                const int r_ = t * RPI + rr;
+                const bool lane_on = EXACT || (rr < RPI && r_ < 32);
+                const int r = lane_on ? r_ : 0, row = rbase + r;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * CW + (((2 * q) ^ (r & 7)) << 2));
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * CW + (((2 * q + 1) ^ (r & 7)) << 2));
-                if (row < p.M && col < p.N && !(p.dbg & 128)) {
+                if (lane_on && row < p.M && col < p.N && !(p.dbg & 128)) {
                     if (p.b32 == FMT_H2) {      // split-f16 operand buffer: [8 x hi][8 x lo] per 8 channels
                         const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         act_store8(p.outB, (size_t)row * p.ldb + col, v8, FMT_H2);
@@ -87,13 +90,16 @@ __device__ __forceinline__ void gemm_store_staged(const GemmArgs& p, f32x16 (&ac
             }
         } else {
             constexpr int RPI = 64 / CPRo;
+            constexpr bool EXACT = 64 % CPRo == 0;         // TN = 3: 48 of the 64 lanes carry a float4 (a lane past them must not repeat a row: res may alias outF)
             const int c = lane % CPRo, rr = lane / CPRo;
             const int col = nw0 + 4 * c;
 #pragma unroll
-            for (int t = 0; t < 32 / RPI; ++t) {
-                const int r = t * RPI + rr, row = rbase + r;
+            for (int t = 0; t < (32 + RPI - 1) / RPI; ++t) {
+                const int r_ = t * RPI + rr;
+                const bool lane_on = EXACT || (rr < RPI && r_ < 32);
+                const int r = lane_on ? r_ : 0, row = rbase + r;
                 f32x4 v = *reinterpret_cast<const f32x4*>(st + r * CW + ((c ^ (r & 7)) << 2));
-                if (row < p.M && col < p.N && !(p.dbg & 128)) {
+                if (lane_on && row < p.M && col < p.N && !(p.dbg & 128)) {
                     if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
                     if (p.outF) {
                         const int orow = p.out_hw ? (row / p.out_hw) * p.out_stride + p.out_off + row % p.out_hw : row;

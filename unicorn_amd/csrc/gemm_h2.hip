@@ -301,6 +301,36 @@ static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+static bool h2_epi_ok(const GemmArgs& a) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return (a.N % 8 == 0) && (!a.bias || al16(a.bias)) && (!a.res || (a.ldr % 4 == 0 && al16(a.res))) &&
+           (!a.outF || (a.ldf % 4 == 0 && al16(a.outF))) && (!a.outB || a.ldb % 8 == 0);
+}
+// small problems (<= 1600 tiles of 64 x 64: the single-frame shapes, the stride-32 level of a batch) run on the deep-pipeline tiles of
+// gemm_h2d.hip: 64 x 64 with 3 slices in flight and 3 blocks per CU up to 800 tiles, 64 x 128 (2 blocks per CU) above
+// (tools/gemm_b1_bench.py, profiles/r03b_b1_gemm_tile_sweep.txt).  Returns 0 (not a deep problem) or the tile configuration.
+// UNI_NO_H2D = A/B switch.
+int gemm_h2d_choice(const GemmArgs& a_in) {
+    static const bool off = getenv("UNI_NO_H2D") != nullptr;
+    if (off || a_in.b32 != FMT_H2) return 0;
+    GemmArgs a = a_in;
+    a.epi = h2_epi_ok(a);
+    if (!gemm_h2d_supported(a, 331)) return 0;
+    const long t64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+    // long-K plain GEMMs with hundreds of 64 x 64 tiles are bound by the L2 -> LDS path on those (4000 x 768 x 3072 = 756 tiles x 96 slices
+    // x 16 KiB = 1.16 GB per launch, ~14.5 TB/s): 128 x 96 / 128 x 128 tiles move 0.6x / 0.5x the bytes, one per CU is enough when they
+    // fill one round (in the model, per frame: 74 us on 256 tiles of 128 x 96 vs 85 us before, 89 us on 64 x 64)
+    const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
+    if (!conv && a.K >= 2048 && t64 > 400 && t64 <= 800) {
+        const long t96 = (long)cdiv(a.M, 128) * cdiv(a.N, 96), t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        if (a.N % 96 == 0 && t96 > 192 && t96 <= 256) return 323;
+        if (t128 > 192 && t128 <= 256) return 322;
+    }
+    if (t64 <= 800) return 331;
+    if (t64 <= 1600) return (a.N % 128 == 0 || a.N % 128 > 64) ? 332 : 331;
+    return 0;
+}
+
 // called by launch_gemm (gemm.hip) for FMT_H2 problems after the common argument checks
 int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
@@ -309,11 +339,7 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
     if (conv) UNI_REQUIRE(a.Cin % 8 == 0 && a.K == a.KH * a.KW * a.Cin && a.Wout < 4096 && a.Mper / a.Wout < 4096, "gemm(h2): conv K mismatch / map too large");
     if (a.stats) UNI_REQUIRE(a.cpg > 0 && 128 / a.cpg + 2 <= 64 && a.act == ACT_NONE, "gemm(h2): cpg=%d / activation with GroupNorm statistics", a.cpg);
     if (a.outB) UNI_REQUIRE(a.N % 8 == 0 && a.ldb % 8 == 0 && ((uintptr_t)a.outB & 31) == 0, "gemm(h2): operand-format output needs N, ldb multiples of 8");
-    {
-        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        a.epi = (a.N % 8 == 0) && (!a.bias || al16(a.bias)) && (!a.res || (a.ldr % 4 == 0 && al16(a.res))) &&
-                (!a.outF || (a.ldf % 4 == 0 && al16(a.outF))) && (!a.outB || a.ldb % 8 == 0);
-    }
+    a.epi = h2_epi_ok(a);
     // tile choice: same reasoning as the bf16 kernel (largest tile that still gives >= ~1.5 blocks per CU); a step of the
     // split kernel carries 3x the MFMA work per byte, so the 256 x 256 tile pays off from fewer blocks on
     const long b44 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
@@ -330,6 +356,7 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
         // the persistent ping-pong kernel runs the K ranges as work units (its deep DMA stream is what small-M problems lack: the
         // generic tiles pay a full load latency per K step); everything it does not cover takes 128 x 128 (128 x 64) tiles
         // (measured, tools/gemm_b1_bench.py: implicit GEMMs do better on the 128 x 128 tiles, plain GEMMs with long K on the ping-pong kernel)
+        if (cfg == 0 && gemm_h2d_choice(a)) return launch_gemm_h2d(a, 331, conv, s);      // few tiles: the K ranges are the extra blocks
         if ((cfg == 0 && !conv && a.K >= 6144) || cfg == 188) {
             GemmArgs g = gemm_splitk_partial_args(a);
             g.splitk = 0;
@@ -338,8 +365,10 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
             if (!no_q && a.N > 64 && a.K % 32 == 0 && nks % a.splitk == 0 && nks / a.splitk >= 2 && gemm_h2q_supported(g)) return launch_gemm_h2q(a, s);
             UNI_REQUIRE(cfg != 188, "gemm(h2): ping-pong split-K does not support this problem");
         }
+        if (gemm_h2d_has_cfg(cfg)) return launch_gemm_h2d(a, cfg, conv, s);
         if (cfg == 0 || cfg == 44 || cfg == 188) cfg = (a.N <= 64) ? 21 : 22;
     }
+    if (gemm_h2d_has_cfg(cfg)) return launch_gemm_h2d(a, cfg, conv, s);
     if (cfg == 0) {
         if (a.N <= 64) cfg = (cdiv(a.M, 128) >= 256) ? 21 : 11;
         else if (util44 >= 0.74 && b44 >= 384 && a.epi) cfg = 44;
@@ -351,6 +380,10 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
         else cfg = b21 >= 400 ? 21 : 11;
     }
     if (!a.epi && cfg == 44) cfg = 22;
+    if (a.force_cfg % 1000 == 0 && cfg != 44) {
+        const int d = gemm_h2d_choice(a);
+        if (d) return launch_gemm_h2d(a, d, conv, s);
+    }
     // problems that take the 256 x 256 tile go to the persistent ping-pong kernel (gemm_h2q.hip, cfg 188) where it covers them; UNI_NO_H2Q = A/B switch
     if (cfg == 44 && a.force_cfg % 1000 == 0) {
         static const bool no_q = getenv("UNI_NO_H2Q") != nullptr;

@@ -37,6 +37,11 @@ void pack_weight_h2_host(const float* w, int N, int Cin, int KH, int KW, const f
                          int Npad, int Kpad);
 int launch_gemm_p44(const GemmArgs& a, hipStream_t s);    // gemm_p44.hip: persistent 256x256 tiles (bf16), next tile prefetched before the drain
 bool gemm_p44_supported(const GemmArgs& a);
+// deep-pipeline 4-wave tiles for launches with <= ~1 block per CU (gemm_h2d.hip); cfg 322 / 323 / 321 / 312 / 311
+bool gemm_h2d_has_cfg(int cfg);
+bool gemm_h2d_supported(const GemmArgs& a, int cfg);
+int gemm_h2d_choice(const GemmArgs& a);      // 0 or the deep tile configuration the launcher takes for this problem
+int launch_gemm_h2d(const GemmArgs& a, int cfg, bool conv, hipStream_t s);
 GemmArgs gemm_splitk_partial_args(const GemmArgs& a);    // the launch that fills the slab: fp32 partial tiles only (no bias / residual / statistics / remap)
 int launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 int launch_gemm_h2q(const GemmArgs& a, hipStream_t s);    // gemm_h2q.hip: persistent 256x256, two wave groups ping-pong MFMA / LDS phases, counted-vmcnt DMA stream
