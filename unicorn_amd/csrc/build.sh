@@ -16,5 +16,5 @@ for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/gemm_h2.o build/gemm_h2d.o build/gemm_h2q.o build/gemm_p44.o build/mlp_fused.o build/norm.o build/msda.o build/corr.o build/misc.o build/post.o build/mask_post.o build/engine.o build/api.o -o $OUT/libunicorn_hip.so
 echo "built $OUT/libunicorn_hip.so"
 # host-side association library (row N2): plain C++, no HIP
-g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -o $OUT/libunicorn_assoc.so assoc.cpp
+g++ -O3 -std=c++17 -fPIC -shared -ffp-contract=off -o $OUT/libunicorn_assoc.so assoc.cpp
 echo "built $OUT/libunicorn_assoc.so"
