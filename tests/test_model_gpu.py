@@ -589,10 +589,12 @@ def test_raw_outputs_decode_in_inference_false():
         mm.head(fpn, pri, mode="mot")
 
 
-@pytest.mark.parametrize("env", [{"UNI_MLP_LAYOUT": "0"}, {"UNI_NO_MLP_FUSED": "1", "UNI_NO_SPLITK": "1"}], ids=["mlp32", "unfused_nosplit"])
+@pytest.mark.parametrize("env", [{"UNI_MLP_LAYOUT": "0"}, {"UNI_NO_MLP_FUSED": "1", "UNI_NO_SPLITK": "1"}, {"UNI_NO_H2D": "1"}],
+                         ids=["mlp32", "unfused_nosplit", "no_deep_tiles"])
 def test_engine_ab_switches_keep_parity(env):
     """The launch-plan switches of the engine (read when the weights are packed / per call) select kernels that are no longer the
-    default: the 32-row fused MLP (UNI_MLP_LAYOUT=0), the two-launch MLP and unsplit single-frame convolutions.  The large SOT parity
+    default: the 32-row fused MLP (UNI_MLP_LAYOUT=0), the two-launch MLP and unsplit single-frame convolutions, the generic two-stage
+    tiles instead of the deep-pipeline ones (UNI_NO_H2D=1).  The large SOT parity
     test must pass with each of them."""
     import subprocess
     import sys
