@@ -380,6 +380,15 @@ int launch_gemm_h2(const GemmArgs& a_in, hipStream_t s) {
         else cfg = b21 >= 400 ? 21 : 11;
     }
     if (!a.epi && cfg == 44) cfg = 22;
+    // 256-wide problems whose N is a multiple of 192 but pads the 256 x 256 tiles (N = 192, 384: a quarter of the MFMA work on zeros) or
+    // leaves the last round of them mostly empty: 256 x 192 tiles of the deep kernel (8 waves, 2 slots; ~0.82 of the ping-pong kernel's
+    // rate per useful flop).  Rounds-aware cost: rounds x tile area / efficiency.  UNI_NO_H2D_192 = A/B switch.
+    if (a.force_cfg % 1000 == 0 && cfg == 44 && a.N % 192 == 0 && gemm_h2d_supported(a, 346)) {
+        static const bool off = getenv("UNI_NO_H2D_192") != nullptr || getenv("UNI_NO_H2D") != nullptr;
+        const long t192 = (long)cdiv(a.M, 256) * (a.N / 192);
+        const double cost_q = (double)cdiv((int)b44, 256) * 65536.0, cost_192 = (double)cdiv((int)t192, 256) * 49152.0 / 0.82;
+        if (!off && cost_192 < 0.97 * cost_q) return launch_gemm_h2d(a, 346, conv, s);
+    }
     if (a.force_cfg % 1000 == 0 && cfg != 44) {
         const int d = gemm_h2d_choice(a);
         if (d) return launch_gemm_h2d(a, d, conv, s);

@@ -40,14 +40,14 @@ __device__ __forceinline__ void d_wait_slices(int ahead) {
 }  // namespace
 
 template <int WM, int WN, int TM, int TN, bool CONV, bool STATS, int NST>
-__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_h2d_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 2 : 1)) void gemm_h2d_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int BKE = 32, ROWB = 128, CPR = 8, RPP = 8;
     constexpr int A_PC = BM / RPP / NW, B_PC = BN / RPP / NW, PER = A_PC + B_PC;
     constexpr int STAGE = (BM + BN) * ROWB;
     static_assert(A_PC >= 1 && B_PC >= 1 && BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile vs wave grid");
-    static_assert(NST >= 3 && (NST - 2) * PER <= 63, "ring depth vs the 6-bit vmcnt");
+    static_assert(NST >= 2 && (NST - 2) * PER <= 63, "ring depth vs the 6-bit vmcnt");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_h2d_kernel(GemmArgs p) {
     // num_records and read zeros -- a request costs one instruction (plus 3 VALU for a conv tap), which matters here: with one wave
     // per SIMD every address instruction is a hole in the MFMA stream.
     const int lrow = lane >> 3;
-    const int lch = (lane & 7) ^ ((4 * wave + (lrow >> 1)) & 7);          // NW = 4: the pieces of a wave are 32 rows apart, same swizzle
-    static_assert(NW == 4, "swizzle term assumes 4 waves");
+    const int lch = (lane & 7) ^ ((4 * wave + (lrow >> 1)) & 7);          // the pieces of a wave are 8 NW rows apart (a multiple of 16): same swizzle
+    static_assert(NW == 4 || NW == 8, "swizzle term assumes 4 or 8 waves");
     const int lda4 = p.lda * 4, ldw4 = p.Kpad * 4;
     char* abase = const_cast<char*>(reinterpret_cast<const char*>(p.A));
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.W)) + (long)n0 * ldw4, 0,
@@ -270,7 +270,7 @@ static int launch_h2d_cfg(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool gemm_h2d_has_cfg(int cfg) { return cfg == 322 || cfg == 323 || cfg == 331 || cfg == 332; }
+bool gemm_h2d_has_cfg(int cfg) { return cfg == 322 || cfg == 323 || cfg == 331 || cfg == 332 || cfg == 346; }
 
 // what the descriptor addressing covers (everything else stays on gemm_h2_kernel)
 bool gemm_h2d_supported(const GemmArgs& a, int cfg) {
@@ -296,6 +296,7 @@ int launch_gemm_h2d(const GemmArgs& a, int cfg, bool conv, hipStream_t s) {
         case 322: GOD(2, 2, 2, 2, 4);
         case 323: GOD(4, 1, 1, 3, 4);
         case 332: GOD(2, 2, 1, 2, 3);
+        case 346: GOD(4, 2, 2, 3, 2);     // 256 x 192, 8 waves, 2 slots
         default: GOD(2, 2, 1, 1, 3);
     }
 #undef GOD
