@@ -287,7 +287,8 @@ bool gemm_h2d_supported(const GemmArgs& a, int cfg) {
 }
 
 // cfg: 322 = 128 x 128 and 323 = 128 x 96 (4-deep ring, one block per CU), 332 = 64 x 128 (3-deep, two per CU), 331 = 64 x 64 (3-deep, three
-// per CU).  (Measured and dropped: 128 x 64, 5-deep 64 x 64, 3-deep 128 x 128 -- never the best choice, tools/gemm_b1_bench.py; 128 x 192 for the
+// per CU), 346 = 256 x 192 (8 waves = two per SIMD, 2 slots of 56 KiB: the K step of a wave is 36 MFMAs, long enough to cover the DMA of the
+// next slice; for 256-wide problems whose N = 192 k pads 256 x 256 tiles -- launch_gemm_h2).  256 x 128 with 3 slots was measured equal to it.  (Measured and dropped: 128 x 64, 5-deep 64 x 64, 3-deep 128 x 128 -- never the best choice, tools/gemm_b1_bench.py; 128 x 192 for the
 // stage-2 pwconv1 of one frame -- 512 tiles = 2 full rounds -- loses to the ping-pong kernel at 75 % fill, 10.2 vs 9.8 ms per frame.)
 int launch_gemm_h2d(const GemmArgs& a, int cfg, bool conv, hipStream_t s) {
     UNI_REQUIRE(gemm_h2d_supported(a, cfg), "gemm(h2, deep): cfg %d does not cover this problem (K %% 32, Cin %% 32, 3x3 taps at most, staged epilogue)", cfg);
