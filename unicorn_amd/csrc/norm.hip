@@ -92,6 +92,11 @@ int launch_layernorm(const LnArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // GroupNorm apply (stats were accumulated by the producing GEMM's epilogue)
 // ------------------------------------------------------------------------------------------------
+// ACT: compile-time activation (ACT_NONE / ACT_RELU / ACT_SILU; -1 = the runtime switch of act_apply for anything else).  FAST: the
+// reciprocal-based activations of the GEMM epilogues (act_fast) -- used whenever the operand format is not exact fp32.  (One kernel with
+// act_apply's runtime switch per element compiled to 5000 instructions and 350 branches: the erff polynomial of a GELU nobody asks for here,
+// IEEE division sequences for SiLU.)
+template <int ACT, bool FAST>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     extern __shared__ float sm[];          // scale[C], shift[C]
     float* scale = sm;
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
         const float pr = p.prior ? p.prior[m] : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float y = act_apply(v[j] * scale[c + j] + shift[c + j], p.act);
+            const float t = v[j] * scale[c + j] + shift[c + j];
+            float y = ACT < 0 ? act_apply(t, p.act) : (FAST ? act_fast<(ACT < 0 ? 0 : ACT)>(t) : act_apply(t, ACT));
             if (p.prior) y += pr * p.prior_beta[c + j];
             v[j] = y;
         }
@@ -175,7 +181,15 @@ int launch_gn_apply(const GnApplyArgs& a, hipStream_t s) {
     const long min_grid = (2048 + nb - 1) / nb;
     if (grid < min_grid) grid = min_grid < (total + 255) / 256 ? min_grid : (total + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)grid, nb), dim3(256), 2 * a.C * sizeof(float), s, a);
+    const bool fast = a.b32 != FMT_F32;
+#define GN_GO(ACT, F) hipLaunchKernelGGL((gn_apply_kernel<ACT, F>), dim3((unsigned)grid, nb), dim3(256), 2 * a.C * sizeof(float), s, a)
+    switch (a.act) {
+        case ACT_NONE: if (fast) GN_GO(ACT_NONE, true); else GN_GO(ACT_NONE, false); break;
+        case ACT_RELU: if (fast) GN_GO(ACT_RELU, true); else GN_GO(ACT_RELU, false); break;
+        case ACT_SILU: if (fast) GN_GO(ACT_SILU, true); else GN_GO(ACT_SILU, false); break;
+        default: GN_GO(-1, false); break;
+    }
+#undef GN_GO
     return 0;
 }
 
