@@ -8,7 +8,8 @@
 // NST-deep LDS ring: requests are counted (`s_waitcnt vmcnt((NST-2) * PER)`: only the OLDEST slice has to have landed), the
 // barrier is a raw `s_barrier` (no vmcnt(0) drain), and the fragments of the second 16-k half are read under the MFMAs of the
 // first.  Tiles: 4 waves, 128 x 128 / 128 x 96 (one block per CU, 4 slices deep) and 64 x 128 / 64 x 64 (3 deep, 2 / 3 blocks per CU)
-// -- 128 x 96 exists because N = 768 over 4000 rows is exactly 256 tiles of it (192 of 128 x 128: a quarter of the chip idle).
+// -- 128 x 96 exists because N = 768 over 4000 rows is exactly 256 tiles of it (192 of 128 x 128: a quarter of the chip idle) -- and
+// 8 waves, 256 x 192 with 2 slots (the 256-wide problems whose N = 192 k would pad the ping-pong kernel's 256 x 256 tiles).
 // Same operand format, loader geometry, swizzle, epilogue (gemm_epi.h) and split-K protocol (slab + splitk_reduce_kernel) as
 // gemm_h2.hip; results are bit-identical to gemm_h2_kernel's for the same K order (same MFMA sequence per accumulator).
 #include "kernels.h"
@@ -27,15 +28,6 @@ __device__ __forceinline__ void d_barrier() {
 template <int N>
 __device__ __forceinline__ void d_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait until at most `ahead` (0 .. MAXA) slices of PER requests each are still in flight
-template <int MAXA, int PER>
-__device__ __forceinline__ void d_wait_slices(int ahead) {
-    if constexpr (MAXA == 0) d_wait_vm<0>();
-    else {
-        if (ahead >= MAXA) d_wait_vm<MAXA * PER>();
-        else d_wait_slices<MAXA - 1, PER>(ahead);
-    }
 }
 }  // namespace
 
