@@ -170,3 +170,7 @@ if __name__ == "__main__":
     dump_specs()
     run_sot("unicorn_track_tiny", 320, 320)
     run_sot("unicorn_track_tiny_mask", 320, 320)
+    # the headline model and its mask / MOT-challenge (num_classes = 1) variants: the real reference on CPU at 320x320
+    run_sot("unicorn_track_large", 320, 320)
+    run_sot("unicorn_track_large_mask", 320, 320)
+    run_sot("unicorn_track_large_mot_challenge", 320, 320)
