@@ -179,17 +179,17 @@ int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre
 /* ---- mask post-processing of the VOS / MOTS drivers -------------------------------------------- */
 /* masks (N,Hn,Wn) fp32 at network resolution -> F.interpolate(scale_factor=1/r, bilinear, align_corners=False)[:, :H, :W]
  * pasted into zero (N,H,W) maps: out_prob fp32 (external/lib/test/tracker/unicorn_vos.py:146-150) and / or
- * out_bin = prob > thr as bytes (unicorn/evaluators/mot_evaluator.py:803-804).  Either output may be NULL. */
+ * out_bin = prob > thr as bytes (unicorn/evaluators/mot_evaluator.py:804-805).  Either output may be NULL. */
 int uni_mask_resize(const float* masks, int N, int Hn, int Wn, double r, int H, int W, float thr, float* out_prob,
                     uint8_t* out_bin, uni_stream_t stream);
-/* Soft aggregation of unicorn_vos.py:99-121 fused with that resize: probs (K1,Hn,Wn) of the tracked objects (ids prob_ids, in
+/* Soft aggregation of unicorn_vos.py:99-120 fused with that resize: probs (K1,Hn,Wn) of the tracked objects (ids prob_ids, in
  * cur_obj_ids order), init_masks (K2,H,W) {0,1} of objects introduced in this frame (ids init_ids); background =
  * prod(1 - p), argmax over [background, ids] (numpy first-maximum rule) -> out (H,W) uint8 id map. */
 int uni_vos_merge(const float* probs, const int32_t* prob_ids, int K1, int Hn, int Wn, double r, const uint8_t* init_masks,
                   const int32_t* init_ids, int K2, int H, int W, uint8_t* out, uni_stream_t stream);
-/* mot_evaluator.py:852-859: masks (N,H,W) {0,1} in track order -> a pixel stays with the first mask that claims it. */
+/* mot_evaluator.py:860-865: masks (N,H,W) {0,1} in track order -> a pixel stays with the first mask that claims it. */
 int uni_mots_overlap_free(const uint8_t* masks, int N, int H, int W, uint8_t* out, uni_stream_t stream);
-/* pycocotools rleEncode + rleToString of np.asfortranarray(mask) (mot_evaluator.py:884-890): out_chars (N,max_chars) bytes,
+/* pycocotools rleEncode + rleToString of np.asfortranarray(mask) (mot_evaluator.py:889-892): out_chars (N,max_chars) bytes,
  * out_len (N) string lengths (-1: more than max_runs runs or max_chars chars, retry with larger bounds); optional
  * counts (N,max_runs+1) uint32 run lengths and n_runs (N). */
 size_t uni_rle_workspace_bytes(int N, int H, int W, int max_runs);

@@ -5,11 +5,11 @@ functions BIT-EXACTLY; the float part (bilinear resize) is written with an expli
 repeats without FMA contraction, and is itself held to torch's F.interpolate (<= 1 ulp) in tests/test_mask_oracle_cpu.py.
 
   resize_bilinear        F.interpolate(mask, scale_factor=1/r, mode="bilinear", align_corners=False)[:, 0, :H, :W]
-                         (external/lib/test/tracker/unicorn_vos.py:146-150, unicorn/evaluators/mot_evaluator.py:803-804)
-  soft_aggregate         unicorn_vos.py:99-121 (background = prod(1 - p), argmax over [background, ids], id map)
-  overlap_free           mot_evaluator.py:852-859 (earlier tracks win overlapping pixels)
+                         (external/lib/test/tracker/unicorn_vos.py:146-150, unicorn/evaluators/mot_evaluator.py:804-805)
+  soft_aggregate         unicorn_vos.py:99-120 (background = prod(1 - p), argmax over [background, ids], id map)
+  overlap_free           mot_evaluator.py:860-865 (earlier tracks win overlapping pixels)
   rle_encode / rle_string / rle_decode
-                         pycocotools.mask.encode on a Fortran-ordered mask + the "counts" string (mot_evaluator.py:884-890).
+                         pycocotools.mask.encode on a Fortran-ordered mask + the "counts" string (mot_evaluator.py:889-892).
                          pycocotools is third-party and absent offline: restated from its published maskApi.c (rleEncode,
                          rleToString, rleFrString) -> "parity unpinned" for the byte format itself; pinned by the
                          round trip decode(encode(m)) == m through the independent rleFrString restatement and by the
@@ -54,7 +54,7 @@ def resize_bilinear(m: np.ndarray, r: float, H: int, W: int) -> np.ndarray:
 
 
 def soft_aggregate(probs: np.ndarray, prob_ids, init_masks=None, init_ids=()):
-    """unicorn_vos.py:99-121.  probs (K1, H, W) float32 probabilities of the tracked objects (list order = cur_obj_ids order),
+    """unicorn_vos.py:99-120.  probs (K1, H, W) float32 probabilities of the tracked objects (list order = cur_obj_ids order),
     init_masks (K2, H, W) {0,1} masks of objects introduced in this frame.  Background = prod over the list of (1 - p) in
     fp32; np.argmax over channels [0 = background, id = its map] (first maximum wins: background, then the lowest id)."""
     probs = np.asarray(probs, dtype=np.float32)
@@ -79,7 +79,7 @@ def soft_aggregate(probs: np.ndarray, prob_ids, init_masks=None, init_ids=()):
 
 
 def overlap_free(masks: np.ndarray) -> np.ndarray:
-    """mot_evaluator.py:852-859: masks (N, H, W) {0,1}, in track order; a pixel stays with the FIRST mask that claims it"""
+    """mot_evaluator.py:860-865: masks (N, H, W) {0,1}, in track order; a pixel stays with the FIRST mask that claims it"""
     masks = np.asarray(masks) != 0
     out = masks.copy()
     prev = np.zeros(masks.shape[1:], dtype=bool)
@@ -149,5 +149,5 @@ def rle_decode(cnts, h: int, w: int) -> np.ndarray:
 
 
 def mask_to_rle_string(mask: np.ndarray) -> bytes:
-    """np.asfortranarray(mask) -> rletools.encode(mask)["counts"] (mot_evaluator.py:884-890)"""
+    """np.asfortranarray(mask) -> rletools.encode(mask)["counts"] (mot_evaluator.py:889-892)"""
     return rle_string(rle_encode(mask))

@@ -635,7 +635,7 @@ def vos_track_frame(P, cfg, state, img: Tensor, info: Optional[dict] = None, r: 
             state["lbs"][k] = label_map_s8(info["init_bbox"][k] * r, Hn, Wn)
             final[k] = (np.asarray(info["init_mask"]) == int(k))
         cur_ids = cur_ids + list(info["init_object_ids"])
-    return vos_merge({k: final[k] for k in cur_ids}, H, W)                           # :99-121
+    return vos_merge({k: final[k] for k in cur_ids}, H, W)                           # :99-120
 
 
 def vos_merge(prob: dict, H: int, W: int):

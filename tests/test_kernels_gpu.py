@@ -811,6 +811,31 @@ def test_vos_merge_device(L):
     assert np.array_equal(vos_merge(torch.from_numpy(probs).cuda(), ids, r, H, W).cpu().numpy(), ref2)
 
 
+def test_vos_mots_device_vs_reference_line_goldens(L, golden_dir):
+    """the device kernels against outputs of the reference's OWN lines (tests/golden/make_golden_vos.py execs
+    unicorn_vos.py:99-120 and mot_evaluator.py:804-805 / 860-865): bit-identical id maps, thresholded masks, overlap-free masks"""
+    from unicorn_amd.ops import vos_merge, mots_overlap_free
+    from unicorn_amd.utils.masks import mots_threshold
+    g = np.load(os.path.join(golden_dir, "vos_mots_ref.npz"))
+    for tag in "abcd":
+        probs, ids = g["vos_%s_probs" % tag], [str(k) for k in g["vos_%s_ids" % tag]]
+        init, init_ids = g["vos_%s_init" % tag], [str(k) for k in g["vos_%s_init_ids" % tag]]
+        ref = g["vos_%s_final" % tag]
+        H, W = ref.shape
+        got = vos_merge(torch.from_numpy(probs).cuda(), ids, 1.0, H, W,
+                        torch.from_numpy(init).cuda() if len(init_ids) else None, init_ids).cpu().numpy()
+        assert np.array_equal(got, ref), tag
+        prob = g["mots_%s_prob" % tag]
+        scale, img_h, img_w = g["mots_%s_geom" % tag]
+        shape = tuple(int(v) for v in g["mots_%s_shape" % tag])
+        n = int(np.prod(shape))
+        mref = np.unpackbits(g["mots_%s_masks" % tag])[:n].reshape(shape)
+        fref = np.unpackbits(g["mots_%s_free" % tag])[:n].reshape(shape)
+        m = mots_threshold(torch.from_numpy(prob)[:, None].cuda(), float(scale), int(img_h), int(img_w), 0.5)
+        assert tuple(m.shape) == shape and np.array_equal(m.cpu().numpy(), mref), tag
+        assert np.array_equal(mots_overlap_free(m).cpu().numpy(), fref), tag
+
+
 def test_mots_overlap_free_and_rle_device(L):
     from unicorn_amd.ops import mots_overlap_free, rle_encode
     g = np.random.default_rng(4)
@@ -835,7 +860,7 @@ def test_mots_overlap_free_and_rle_device(L):
 
 
 def test_mots_mask_pipeline_device(L):
-    """mot_evaluator.py:803-804 + :850-863 + :884-890 composed (unicorn_amd/utils/masks.py) vs the oracle composition"""
+    """mot_evaluator.py:804-805 + :850-863 + :889-892 composed (unicorn_amd/utils/masks.py) vs the oracle composition"""
     from unicorn_amd.utils.masks import mots_rle, mots_threshold
     g = torch.Generator().manual_seed(9)
     Hn, Wn, scale, h, w = 100, 160, 0.74, 130, 210
@@ -937,7 +962,7 @@ def test_mlp_fused_matches_unfused_pair(L):
 
 
 def test_mots_threshold_matches_reference_crop_shape():
-    """mot_evaluator.py:803-804 on a 480 x 854 image at 800 x 1280: F.interpolate(scale_factor=1/scale) yields 480 x 853, so the
+    """mot_evaluator.py:804-805 on a 480 x 854 image at 800 x 1280: F.interpolate(scale_factor=1/scale) yields 480 x 853, so the
     reference thresholds and RLE-encodes a (480, 853) mask.  mots_threshold(crop=True) returns that shape with identical bits;
     crop=False is the zero-padded full-size map of the VOS driver."""
     from unicorn_amd.utils.masks import mots_threshold

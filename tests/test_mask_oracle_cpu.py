@@ -1,5 +1,6 @@
 """oracle/mask_oracle.py (row N1 restatements) pinned on the CPU: the bilinear resize against torch's own F.interpolate, the
-soft aggregation against the literal numpy lines of unicorn_vos.py:99-121, the RLE codec by hand-derived strings and the
+soft aggregation, the MOTS threshold and the overlap-free merge against outputs of the reference's OWN lines (exec'd by
+tests/golden/make_golden_vos.py: unicorn_vos.py:99-120, mot_evaluator.py:804-805, 860-865), the RLE codec by hand-derived strings and the
 encode -> decode round trip through the independent rleFrString restatement."""
 import numpy as np
 import torch
@@ -21,18 +22,44 @@ def test_resize_matches_torch_interpolate():
         assert (got[:, hh:] == 0).all() and (got[:, :, ww:] == 0).all()
 
 
+def _gold():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vos_mots_ref.npz"))
+
+
 def test_soft_aggregate_matches_reference_lines():
-    g = np.random.default_rng(1)
-    H, W = 40, 56
-    probs = g.random((3, H, W), dtype=np.float32)
-    probs[0, :5] = 0.0
-    probs[1, 5:9] = 1.0
-    ids = ["2", "5", "3"]
-    init = (g.random((1, H, W)) > 0.7)
-    got = mo.soft_aggregate(probs, ids, init, ["7"])
-    d = {k: probs[i] for i, k in enumerate(ids)}
-    d["7"] = init[0]
-    assert np.array_equal(got, uo.vos_merge(d, H, W))                 # the restatement of unicorn_vos.py:99-121 used by the model tests
+    """external/lib/test/tracker/unicorn_vos.py:99-120 EXEC'D from the reference tree (tests/golden/make_golden_vos.py): tracked
+    objects, objects of later reference groups, objects introduced in this frame, exact ties, certain rows -- against both
+    restatements (mask_oracle.soft_aggregate = what the HIP merge kernel is held to, unicorn_oracle.vos_merge = what the model
+    tests use)."""
+    g = _gold()
+    for tag in "abcd":
+        probs, ids = g["vos_%s_probs" % tag], [str(k) for k in g["vos_%s_ids" % tag]]
+        init, init_ids = g["vos_%s_init" % tag], [str(k) for k in g["vos_%s_init_ids" % tag]]
+        ref = g["vos_%s_final" % tag]
+        got = mo.soft_aggregate(probs, ids, init, init_ids)
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), tag
+        d = {k: probs[i] for i, k in enumerate(ids)}
+        for j, k in enumerate(init_ids):
+            d[k] = init[j] != 0
+        assert np.array_equal(uo.vos_merge(d, *ref.shape), ref), tag
+
+
+def test_mots_threshold_and_overlap_free_match_reference_lines():
+    """unicorn/evaluators/mot_evaluator.py:804-805 (resize by 1/scale, crop, > mask_thres) and :860-865 (overlap-free masks)
+    EXEC'D from the reference tree on smooth probability maps that cross the threshold."""
+    g = _gold()
+    for tag in "abcd":
+        prob = g["mots_%s_prob" % tag]
+        scale, img_h, img_w = g["mots_%s_geom" % tag]
+        shape = tuple(int(v) for v in g["mots_%s_shape" % tag])
+        n = int(np.prod(shape))
+        ref = np.unpackbits(g["mots_%s_masks" % tag])[:n].reshape(shape)
+        free = np.unpackbits(g["mots_%s_free" % tag])[:n].reshape(shape)
+        up = mo.resize_bilinear(prob, float(scale), int(img_h), int(img_w))[:, :shape[1], :shape[2]]
+        got = (up > np.float32(0.5)).astype(np.uint8)
+        assert np.array_equal(got, ref), (tag, int((got != ref).sum()))
+        assert np.array_equal(mo.overlap_free(ref), free), tag
 
 
 def test_rle_hand_checked_and_round_trip():

@@ -94,10 +94,14 @@ def hip_sot_step(m, cfg, frames, box):
 EXACT = ("fp32", "f16x2")      # precision modes that must meet the north_star bar
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
-@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask"])
+GOLDEN_CASES = [(e, p) for e in ("unicorn_track_tiny", "unicorn_track_tiny_mask") for p in ("fp32", "f16x2", "bf16")] + \
+    [(e, "f16x2") for e in ("unicorn_track_large", "unicorn_track_large_mask", "unicorn_track_large_mot_challenge")]
+
+
+@pytest.mark.parametrize("exp,precision", GOLDEN_CASES)
 def test_tiny_320_vs_reference_golden(exp, precision, golden_dir):
-    """BASELINE.json configs[0] shapes; expected values come from the real reference (tests/golden/make_golden.py)."""
+    """BASELINE.json configs[0] shapes; expected values come from the real reference (tests/golden/make_golden.py): the tiny
+    models in all three precisions, the headline `unicorn_track_large` family in the headline precision."""
     g = np.load(os.path.join(golden_dir, "%s_320x320.npz" % exp))
     m, cfg, P = build(exp, precision)
     frames, box = synth.synth_clip(320, 320, 2, seed=1)

@@ -1,11 +1,11 @@
 // Row N1 (remainder): mask post-processing of the VOS / MOTS drivers on the device -- integer / byte work, bit-exact against
 // oracle/mask_oracle.py:
 //   mask_resize_kernel     F.interpolate(mask, scale_factor=1/r, "bilinear", align_corners=False)[:, 0, :H, :W] pasted into a zero
-//                          (H, W) map; float output (unicorn_vos.py:146-150) or `> thr` bytes (mot_evaluator.py:803-804)
-//   vos_merge_kernel       the same resize fused with the soft aggregation of unicorn_vos.py:99-121: background = prod(1 - p),
+//                          (H, W) map; float output (unicorn_vos.py:146-150) or `> thr` bytes (mot_evaluator.py:804-805)
+//   vos_merge_kernel       the same resize fused with the soft aggregation of unicorn_vos.py:99-120: background = prod(1 - p),
 //                          argmax over [background, ids] -> (H, W) uint8 id map (never materialises the (H, W, K+1) float64 cube)
-//   overlap_free_kernel    mot_evaluator.py:852-859: a pixel stays with the first track that claims it
-//   rle_*                  pycocotools rleEncode (column-major runs) + rleToString (mot_evaluator.py:884-890)
+//   overlap_free_kernel    mot_evaluator.py:860-865: a pixel stays with the first track that claims it
+//   rle_*                  pycocotools rleEncode (column-major runs) + rleToString (mot_evaluator.py:889-892)
 // HBM-bound streaming kernels: coalesced along x, one pass over the inputs.
 #include "kernels.h"
 

@@ -175,7 +175,7 @@ def letterbox(image, input_size, swap_rb=True, device=None):
 # ---------------------------------------------------------------------------------------------------------------------
 def mask_resize(masks, r, H, W, thr=None):
     """masks (N, Hn, Wn) fp32 cuda -> F.interpolate(masks[:, None], scale_factor=1/r, bilinear)[:, 0, :H, :W] pasted into zero
-    (N, H, W) maps (unicorn_vos.py:146-150); with thr: the `> thr` byte masks of mot_evaluator.py:803-804 instead."""
+    (N, H, W) maps (unicorn_vos.py:146-150); with thr: the `> thr` byte masks of mot_evaluator.py:804-805 instead."""
     _need_cuda(masks)
     m = masks.float().contiguous()
     N, Hn, Wn = m.shape
@@ -191,7 +191,7 @@ def mask_resize(masks, r, H, W, thr=None):
 
 
 def vos_merge(probs, prob_ids, r, H, W, init_masks=None, init_ids=()):
-    """soft aggregation of unicorn_vos.py:99-121 fused with the 1/r resize: probs (K1, Hn, Wn) network-resolution mask
+    """soft aggregation of unicorn_vos.py:99-120 fused with the 1/r resize: probs (K1, Hn, Wn) network-resolution mask
     probabilities of the tracked objects (ids prob_ids, cur_obj_ids order), init_masks (K2, H, W) of objects introduced in
     this frame -> (H, W) uint8 id map on the device."""
     dev = probs.device if probs is not None else init_masks.device
@@ -209,7 +209,7 @@ def vos_merge(probs, prob_ids, r, H, W, init_masks=None, init_ids=()):
 
 
 def mots_overlap_free(masks):
-    """mot_evaluator.py:852-859: (N, H, W) bool/uint8 masks in track order -> earlier tracks keep overlapping pixels"""
+    """mot_evaluator.py:860-865: (N, H, W) bool/uint8 masks in track order -> earlier tracks keep overlapping pixels"""
     _need_cuda(masks)
     m = masks.to(torch.uint8).contiguous()
     out = torch.empty_like(m)
@@ -220,7 +220,7 @@ def mots_overlap_free(masks):
 
 def rle_encode(masks, max_runs=1 << 14):
     """pycocotools.mask.encode(np.asfortranarray(mask))["counts"] for every (H, W) mask of an (N, H, W) {0,1} cuda tensor
-    (mot_evaluator.py:884-890) -> list of bytes objects.  Runs are found and the strings are written on the device; one
+    (mot_evaluator.py:889-892) -> list of bytes objects.  Runs are found and the strings are written on the device; one
     read-back of lengths + chars."""
     _need_cuda(masks)
     m = masks.to(torch.uint8).contiguous()

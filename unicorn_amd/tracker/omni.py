@@ -4,7 +4,7 @@
 interaction(previous frame, current frame) -> ONE embedding upsample -> instance embeddings at the box centres (:1024-1034) ->
 rescale to the original image -> QuasiDenseEmbedTracker.match -> valid ids.
 `OmniMOTSFrame.run` = :770-890 (the MOTS twin): postprocess_inst + CondInst masks, `> mask_thres` at the original resolution,
-match(return_index=True), masks reordered to ascending track id, overlap-free merge (:852-859), pycocotools RLE strings (:884-890).
+match(return_index=True), masks reordered to ascending track id, overlap-free merge (:860-865), pycocotools RLE strings (:889-892).
 
 The evaluator classes themselves (data loader, result files, TrackEval glue) are out of scope; these two callables
 are what their loop bodies do per frame, with every tensor step on unicorn_amd kernels.  Time-batching: `run_batch` takes B
@@ -109,7 +109,7 @@ class OmniMOTSFrame(OmniMOTFrame):
                 res.append(([], []))
                 continue
             bboxes, scores = det[:, :4], det[:, 4:5] * det[:, 5:6]
-            masks = mots_threshold(om[0], scale, int(img_h), int(img_w), self.mask_thres)   # :803-804 (uni_mask_resize)
+            masks = mots_threshold(om[0], scale, int(img_h), int(img_w), self.mask_thres)   # :804-805 (uni_mask_resize)
             keep = scores[:, 0] > self.embed_score_thr
             bboxes, scores, masks = bboxes[keep], scores[keep], masks[keep]
             labels = torch.ones((bboxes.size(0),))
@@ -126,7 +126,7 @@ class OmniMOTSFrame(OmniMOTFrame):
             _, inds = out_ids.sort(descending=False)                                        # :853-856
             out_ids, out_b = out_ids[inds], out_b[inds]
             self.t.mark("association")
-            free, rles = mots_rle(masks, order=idx[inds].tolist())                          # :857-863 + :884-890 on the device
+            free, rles = mots_rle(masks, order=idx[inds].tolist())                          # :860-865 + :889-892 on the device
             ids, keep_rle = [], []
             for i in range(out_b.shape[0]):
                 x1, y1, x2, y2 = [float(v) for v in out_b[i, :4]]

@@ -3,7 +3,7 @@
 Same control flow as the reference driver: objects of the first frame form the first reference group, objects that appear
 mid-sequence (`info["init_object_ids"]` / `init_bbox` / `init_mask` passed to `track`, :87-98) get the frame they appear in as
 their own reference (`out_dict_pre_new` / `obj_ids_new`), every frame runs `get_det_results` once per group and the per-object
-mask probabilities are soft-aggregated into one id map (:99-121).
+mask probabilities are soft-aggregated into one id map (:99-120).
 
 What differs is where the work happens (rows N3 / N1 of SURVEY.md §8f):
   * per group, interaction + the two embedding upsamples + the HW x HW correlation run ONCE, with the K label maps of the
@@ -152,7 +152,7 @@ class UnicornVOSTrack:
                 self.lbs_pre_dict[k] = self._label(info["init_bbox"][k], r)
             im = torch.as_tensor(np.asarray(info["init_mask"])).to(self.device)
             init_masks = torch.stack([(im == int(k)) for k in init_ids]).to(torch.uint8)
-        # soft aggregation on the device (:99-121); objects without a detection contribute an all-zero map, i.e. nothing
+        # soft aggregation on the device (:99-120); objects without a detection contribute an all-zero map, i.e. nothing
         live = [k for k in order if probs[k] is not None]
         pt = torch.stack([probs[k] for k in live]) if live else None
         if pt is None and not init_ids:

@@ -1,9 +1,9 @@
 """Mask post-processing of the MOTS evaluator (unicorn/evaluators/mot_evaluator.py:803-890) on the device (row N1).
 
-    masks = F.interpolate(outputs_mask[0], scale_factor=1/scale, bilinear)[:, 0, :img_h, :img_w] > mask_thres     (:803-804)
+    masks = F.interpolate(outputs_mask[0], scale_factor=1/scale, bilinear)[:, 0, :img_h, :img_w] > mask_thres     (:804-805)
     ... association picks / reorders the masks (indexs, valid_inds, ascending track id)                              (:843-856)
-    overlap-free: masks_new[n] = masks[n] & ~(masks[0] | ... | masks[n-1])                                          (:857-863)
-    rle = pycocotools.mask.encode(np.asfortranarray(mask))["counts"].decode("utf-8")                                (:884-890)
+    overlap-free: masks_new[n] = masks[n] & ~(masks[0] | ... | masks[n-1])                                          (:860-865)
+    rle = pycocotools.mask.encode(np.asfortranarray(mask))["counts"].decode("utf-8")                                (:889-892)
 
 `mots_threshold` and `mots_rle` wrap the three kernels (uni_mask_resize, uni_mots_overlap_free, uni_rle_encode); only the RLE
 strings (a few KB) leave the device.
@@ -15,7 +15,7 @@ from ..ops import mask_resize, mots_overlap_free, rle_encode
 
 def mots_threshold(outputs_mask, scale, img_h, img_w, mask_thres=0.30, crop=True):
     """outputs_mask (N, 1, Hn, Wn) sigmoid scores of postprocess_inst -> uint8 masks at the original resolution
-    (mot_evaluator.py:803-804): F.interpolate(scale_factor=1/scale)[:, 0, :img_h, :img_w] > mask_thres.
+    (mot_evaluator.py:804-805): F.interpolate(scale_factor=1/scale)[:, 0, :img_h, :img_w] > mask_thres.
     The interpolated map has floor(Hn / scale) x floor(Wn / scale) pixels, which can be ONE SHORT of the image (480 x 854 image at
     800 x 1280: 1280 / 1.4988 -> 853): the reference then encodes a (480, 853) mask.  crop=True (default) returns exactly that
     shape, so the RLE strings are the reference's; crop=False returns the zero-padded (N, img_h, img_w) maps the VOS driver
