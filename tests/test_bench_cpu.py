@@ -45,3 +45,52 @@ def test_mix_single_rank_is_sot():
     assert bench.rank_task("mix", "unicorn_track_large", 0, 2) == ("mot", "unicorn_track_large_mot_challenge")
     assert bench.rank_task("mix", "unicorn_track_large", 1, 2) == ("sot", "unicorn_track_large")
     assert bench.rank_task("mot", "unicorn_track_large", 1, 2) == ("mot", "unicorn_track_large")
+
+
+def _run_env(env_extra, *extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-check", *extra], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_rccl_probe_child_processes_run_and_report():
+    """init_dist(): the first RCCL contact happens in one child process per rank (own rendezvous port, timeout, exact-PID kill); here
+    the children rendezvous over gloo (no GPU) and every rank must report a good probe."""
+    r = _run_env({"UNI_BENCH_PROBE": "1"}, "--gpus", "2")
+    assert r["dist"]["rccl_probe"]["ok_all_ranks"] is True and r["dist"]["control"] == "gloo"
+    assert r["n_gpus"] == 2 and r["gathered_rows"] == 3 + 4
+
+
+def test_failed_rccl_probe_degrades_to_the_gloo_gather():
+    """a probe that dies on every rank must not lose the run: the gathers go over gloo and the line says so"""
+    r = _run_env({"UNI_BENCH_PROBE": "1", "UNI_BENCH_PROBE_FAIL": "1"}, "--gpus", "2")
+    assert r["dist"]["rccl_probe"]["ok_all_ranks"] is False and r["dist"]["data"] == "gloo"
+    assert r["n_gpus"] == 2 and r["gathered_rows"] == 3 + 4 and r["gathered_strings"] == 1 + 2
+
+
+def test_timed_loop_keeps_calling_collectives_after_a_rank_error():
+    """N > 1: an exception in a rank's step is recorded and the rank keeps taking part in every gather (with the rows it has), so
+    the other ranks never hang; N = 1 (errs=None): the exception propagates."""
+    sys.path.insert(0, ROOT)
+    import pytest
+    import bench
+
+    class S:
+        n = 0
+
+        def step(self, i):
+            S.n += 1
+            if i == 3:
+                raise RuntimeError("boom")
+
+    calls = []
+    errs = []
+    bench.timed([S()], steps=6, warmup=2, barrier=lambda: None, gather=lambda st: calls.append(1) or 0, gather_every=2, errs=errs)
+    assert len(calls) == 4 and len(errs) == 1 and "boom" in errs[0] and S.n == 4      # steps 0..3 ran, 4..7 skipped, all 4 gathers called
+    with pytest.raises(RuntimeError):
+        bench.timed([S()], steps=6, warmup=2, barrier=lambda: None)

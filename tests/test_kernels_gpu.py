@@ -1018,7 +1018,7 @@ def test_gemm_h2_deep(L, cfg, case):
         stats = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
         L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), wscale, M, N, Hin, Win, Cin, k, k, stride, pad, L.ptr(bias), act,
                                     L.ptr(outF) if use_res else None, N, L.ptr(outF), N, L.ptr(outB), N, L.ptr(stats), (N // G) if G else 0,
-                                    c + (100000 * sk if sk > 1 else 0), L.stream_ptr()), "gemm_h2")
+                                    c + (1000000 * sk if sk > 1 else 0), L.stream_ptr()), "gemm_h2")
         torch.cuda.synchronize()
         return (outB if use_B else outF), stats
 
@@ -1067,7 +1067,7 @@ def test_gemm_h2_splitk(L, case):
         st = torch.zeros(64, device="cuda", dtype=torch.float64) if G else None
         L.check(L.lib().uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), ws, M, N, Hin, Win, Cin, k, k, 1, pad, L.ptr(bias_d), 0,
                                     L.ptr(out) if use_res else None, N, L.ptr(out), N, None, 0, L.ptr(st), N // G if G else 0,
-                                    cfg + (100000 * split if split > 1 else 0), L.stream_ptr()), "gemm_h2")
+                                    cfg + (1000000 * split if split > 1 else 0), L.stream_ptr()), "gemm_h2")
         torch.cuda.synchronize()
         outs.append(out.cpu().double())
         stats.append(None if st is None else st.cpu())

@@ -104,6 +104,7 @@ def test_product_rle_reader_inverts_the_oracle_encoder():
         m[: h // 3] = 0
         s = mo.mask_to_rle_string(m)
         assert np.array_equal(rle_string_to_mask(s, h, w), m)
+        assert np.array_equal(rle_string_to_mask(s.decode("utf-8"), h, w), m)      # mots_rle hands out utf-8 decoded str (mot_evaluator.py:891)
     import pytest
     with pytest.raises(ValueError):
         rle_string_to_mask(mo.mask_to_rle_string(np.ones((4, 4), np.uint8)), 5, 4)

@@ -51,7 +51,7 @@ for name, Hin, Win, Cin, N, k, act, use_res, use_B in SHAPES:
 
             def run():
                 L.check(lib.uni_gemm_h2(L.ptr(A), Cin, L.ptr(Wp), 1.0 / 128, M, N, Hin, Win, Cin, k, k, 1, pad, L.ptr(bias), act, L.ptr(res), N,
-                                        None if use_B else L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg + (100000 * sk if sk > 1 else 0), L.stream_ptr()), "gemm_h2")
+                                        None if use_B else L.ptr(outF), N, L.ptr(outB), N, None, 0, cfg + (1000000 * sk if sk > 1 else 0), L.stream_ptr()), "gemm_h2")
             try:
                 for _ in range(3):
                     run()

@@ -7,6 +7,10 @@
 
 #include "engine.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 static thread_local char g_err[1024] = "";
 void uni_set_error(const char* fmt, ...) {
     va_list ap;
@@ -251,22 +255,27 @@ int uni_gemm_h2(const void* A, int lda, const void* w_packed, float wscale, int 
     UNI_REQUIRE(g.M == M, "gemm_h2: M=%d does not match conv geometry (%d)", M, g.M);
     g.bias = bias; g.act = act; g.res = residual; g.ldr = ldr; g.outF = outF; g.ldf = ldf;
     g.outB = reinterpret_cast<bf16*>(outB); g.ldb = ldb; g.stats = gn_stats; g.cpg = cpg; g.force_cfg = force_cfg;
-    g.b32 = FMT_H2; g.wscale = wscale; g.dbg = (force_cfg / 1000) % 100;
-    g.splitk = force_cfg / 100000;            // tests / tools: force_cfg = tile cfg + 1000 * ablation bits + 100000 * K ranges
+    // tests / tools: force_cfg = tile cfg (< 1000) + 1000 * ablation bits (0..255: gemm_epi.h `dbg & 128`, gemm.hip `& 64`, ...) + 1000000 * K ranges
+    g.b32 = FMT_H2; g.wscale = wscale; g.dbg = (force_cfg / 1000) % 1000;
+    g.splitk = force_cfg / 1000000;
     g.force_cfg = force_cfg % 1000;
     g.Mper = g.M;
-    if (g.splitk > 1) {                       // partial-tile slab of the split-K path: one grow-only buffer for this test / bench entry
-        static float* slab = nullptr;
-        static size_t cap = 0;
+    if (g.splitk > 1) {                       // partial-tile slab of the split-K path: one grow-only buffer PER DEVICE for this test / bench entry
+        static std::mutex mu;                 // (the engine takes its slabs from the context workspace; this entry has no context)
+        static std::map<int, std::pair<float*, size_t>> slabs;
+        int dev = 0;
+        UNI_CHECK_HIP(hipGetDevice(&dev));
         const size_t need = (size_t)g.splitk * g.M * g.N * sizeof(float);
-        if (need > cap) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto& sl = slabs[dev];
+        if (need > sl.second) {
             UNI_CHECK_HIP(hipDeviceSynchronize());
-            if (slab) (void)hipFree(slab);
-            slab = nullptr; cap = 0;
-            UNI_CHECK_HIP(hipMalloc(&slab, need));
-            cap = need;
+            if (sl.first) (void)hipFree(sl.first);
+            sl = {nullptr, 0};
+            UNI_CHECK_HIP(hipMalloc(&sl.first, need));
+            sl.second = need;
         }
-        g.slab = slab;
+        g.slab = sl.first;
     }
     API(launch_gemm(g, S(stream)));
 }

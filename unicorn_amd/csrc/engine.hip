@@ -531,8 +531,9 @@ static GemmArgs conv_args(const PConv& p, ActPtr A, int lda, int Hin, int Win, i
     return g;
 }
 
-// Single-frame (small M) problems leave most of the 256 CUs without a tile: K ranges of one tile then go to different blocks that add
-// their partial products with fp32 atomics (gemm_h2.hip, GemmArgs::splitk).  Returns the number of K ranges (1 = no split).
+// Single-frame (small M) problems leave most of the 256 CUs without a tile: K ranges of one tile then go to different blocks, every
+// block stores its partial tile into a slab and `splitk_reduce_kernel` sums the ranges in a fixed order (deterministic; bias / residual /
+// GroupNorm sums are applied there -- gemm_h2.hip, GemmArgs::splitk).  Returns the number of K ranges (1 = no split).
 // UNI_NO_SPLITK = A/B switch.
 static int choose_splitk(const uni_ctx* c, const GemmArgs& g) {
     static const bool off = getenv("UNI_NO_SPLITK") != nullptr;
@@ -553,7 +554,7 @@ static int choose_splitk(const uni_ctx* c, const GemmArgs& g) {
     } else if (conv) {
         if (tiles > 128 || nk < 24) return 1;
         sk = std::min((int)std::min<long>((400 + tiles / 2) / tiles, nk / 12), 8);
-    } else if (tiles <= 96 && nk >= 192) sk = 4;
+    } else if (tiles <= 96 && nk >= 192) sk = 4;      // only reached with UNI_NO_H2D (gemm_h2d_choice claims every problem this small): plain long-K GEMMs on the generic tiles
     while (sk > 1 && (size_t)sk * g.M * g.N * sizeof(float) > UNI_SLAB_BYTES) --sk;      // the partial-tile slab has a fixed budget in the workspace plan
     return sk >= 2 ? sk : 1;
 }

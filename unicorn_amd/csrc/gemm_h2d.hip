@@ -268,11 +268,12 @@ bool gemm_h2d_has_cfg(int cfg) { return cfg == 322 || cfg == 323 || cfg == 331 |
 bool gemm_h2d_supported(const GemmArgs& a, int cfg) {
     const bool conv = a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0;
     if (!gemm_h2d_has_cfg(cfg) || a.b32 != FMT_H2 || !a.epi || a.K % 32 != 0 || a.K < 64) return false;
-    if ((long)128 * a.lda * 4 >= (1L << 30) || (long)128 * a.Kpad * 4 >= (1L << 30)) return false;
+    const long rows = cfg == 346 ? 256 : 128;    // tallest tile of the configuration (A rows / weight rows addressed from one descriptor base)
+    if (rows * a.lda * 4 >= (1L << 30) || rows * a.Kpad * 4 >= (1L << 30)) return false;
     if (conv) {
         if (a.Cin % 32 != 0 || a.KH > 3 || a.KW > 3 || a.K != a.KH * a.KW * a.Cin || a.Cin / 32 > 448) return false;
-        // the input pixels of one 128-row tile must lie within 2^26 bytes of its first one (the per-lane offsets carry 6 flag bits)
-        const long span_pix = (128L / a.Wout + 2) * a.stride * a.Win + 128L * a.stride + 3L * a.Win;
+        // the input pixels of one row tile must lie within 2^26 bytes of its first one (the per-lane offsets carry 6 flag bits)
+        const long span_pix = (rows / a.Wout + 2) * a.stride * a.Win + rows * a.stride + 3L * a.Win;
         if (span_pix * a.lda * 4 >= (1L << 26)) return false;
     }
     return true;

@@ -206,7 +206,10 @@ class Unicorn:
         return self
 
     def check_saturation(self, on=True):
-        """uni_ctx_set_check: count f16x2 operands that hit the +-65504 saturation bound (resets the counters)."""
+        """uni_ctx_set_check: count f16x2 operands that hit the +-65504 saturation bound (resets the counters).  In check mode the
+        ConvNeXt MLPs run as the two-launch pair (pwconv1+GELU, pwconv2) so that the hidden operand tensor exists to be scanned: the
+        fused-MLP kernel of the production path forms the same hidden operands in registers (same split, same saturation), its
+        outputs agree with the pair to fp32 round-off but are not bit-identical (tests: test_mlp_fused_matches_unfused_pair)."""
         self._require_ready()
         L.check(L.lib().uni_ctx_set_check(self._ctx, int(bool(on))), "uni_ctx_set_check")
         return self

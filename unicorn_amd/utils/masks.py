@@ -49,6 +49,8 @@ def rle_string_to_mask(s, h, w):
     """Inverse of the strings `mots_rle` / `rle_encode` produce (pycocotools maskApi.c rleFrString + rleDecode): compressed counts string
     -> (h, w) uint8 numpy mask, column-major runs starting with zeros.  Host-side reader of gathered result strings."""
     import numpy as np
+    if isinstance(s, str):                      # mots_rle returns utf-8 decoded strings (mot_evaluator.py:891), rle_encode raw bytes
+        s = s.encode("ascii")
     cnts, p = [], 0
     while p < len(s):
         x, k, more = 0, 0, True
