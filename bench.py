@@ -305,6 +305,7 @@ def timed(streams, steps, warmup, barrier, gather=None, gather_every=1, errs=Non
     rows it has) so that the other ranks never hang on it.
     Returns (wall seconds between the barriers, this rank's own busy seconds, gathered row count)."""
     import torch
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)      # (the CPU tests drive this loop with fake streams)
 
     def do(i):
         if errs:                                   # this rank already failed: collectives only
@@ -327,11 +328,11 @@ def timed(streams, steps, warmup, barrier, gather=None, gather_every=1, errs=Non
     for i in range(steps):
         do(warmup + i)
         if gather is not None and (i + 1) % gather_every == 0:
-            torch.cuda.synchronize()               # this rank's own work up to here (the collective below waits for the slowest rank)
+            sync()               # this rank's own work up to here (the collective below waits for the slowest rank)
             own += time.perf_counter() - ta
             nrows += gather(streams)
             ta = time.perf_counter()
-    torch.cuda.synchronize()
+    sync()
     own += time.perf_counter() - ta
     barrier()
     return time.perf_counter() - t0, own, nrows
