@@ -665,6 +665,64 @@ def test_omni_mot_frame_batched_equals_per_frame_and_oracle():
         assert hit == len(mo_), (hit, len(mo_))
 
 
+def test_omni_stream_pipelined_equals_per_frame():
+    """run_stream (software pipeline over the launch stream: A0 A1 B0 A2 | H0 C0 B1 A3 | ...) must give exactly the per-frame results:
+    MOT loop (ids, boxes) and MOTS loop (1-based ids, RLE strings), and the SOT driver's track_stream the boxes of track()."""
+    from unicorn_amd.tracker import OmniMOTFrame, OmniMOTSFrame, QuasiDenseEmbedTracker, UnicornSOTTrack
+    H = W = 320
+    kw = dict(init_score_thr=0.0, obj_score_thr=0.0, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+              memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+              match_metric="bisoftmax")
+    frames, box = synth.synth_clip(H, W, 7, seed=7)
+    fr = [frames[f].cuda() for f in range(1, 7)]
+    info = (480, 480)
+    # ---- MOT
+    m, cfg, P = build("unicorn_track_tiny", "f16x2")
+    with torch.no_grad():
+        o, _ = m(fr[0])
+    sc = (o[0, :, 4] * o[0, :, 5:].max(1)[0]).sort(descending=True)[0]
+    thr = float((sc[59] + sc[60]) / 2)
+    mk = lambda: OmniMOTFrame(m, QuasiDenseEmbedTracker(**kw), (H, W), num_classes=cfg.num_classes, confthre=thr, nmsthre=0.7, embed_score_thr=thr)
+    one, pip = mk(), mk()
+    with torch.no_grad():
+        r1 = [one.run(f, info) for f in fr]
+        rp = [r[0] for r in pip.run_stream(fr, info)]
+    assert len(rp) == len(r1) == 6
+    for (b1, i1), (b2, i2) in zip(r1, rp):
+        assert torch.equal(i1, i2) and torch.equal(b1, b2) and len(i1) > 10
+        assert torch.equal(i1, i1.sort()[0])                          # ascending track ids (mot_evaluator.py:1052-1055)
+    # a high threshold on the score empties some frames: the loop must survive frames without detections (result (None, None))
+    hi = mk()
+    hi.confthre = float(sc[0]) * 1.5
+    with torch.no_grad():
+        assert all(r[0] == (None, None) for r in hi.run_stream(fr[:3], info)) and hi.pre_dict is None and hi.frame_id == 3
+    del m
+    # ---- MOTS
+    mm, cfgm, _ = build("unicorn_track_tiny_mask", "f16x2")
+    with torch.no_grad():
+        o, _ = mm(fr[0])
+    sc = (o[0][0, :, 4] * o[0][0, :, 5:].max(1)[0]).sort(descending=True)[0]
+    thr = float((sc[19] + sc[20]) / 2)
+    mks = lambda: OmniMOTSFrame(mm, QuasiDenseEmbedTracker(**kw), (H, W), num_classes=cfgm.num_classes, confthre=thr, nmsthre=0.7,
+                                embed_score_thr=thr, mask_thres=0.3, d_rate=cfgm.d_rate, min_box_area=10)
+    one, pip = mks(), mks()
+    with torch.no_grad():
+        r1 = [one.run(f, info) for f in fr]
+        rp = [r[0] for r in pip.run_stream(fr, info)]
+    assert [r[0] for r in r1] == [r[0] for r in rp] and [r[1] for r in r1] == [r[1] for r in rp]
+    assert sum(len(r[1]) for r in r1) > 20 and all(isinstance(s_, str) for r in r1 for s_ in r[1])
+    del mm
+    # ---- SOT
+    ms, _, _ = build("unicorn_track_tiny", "f16x2")
+    xywh = [float(box[0]), float(box[1]), float(box[2] - box[0]), float(box[3] - box[1])]
+    a, b = UnicornSOTTrack(ms, input_size=(H, W)), UnicornSOTTrack(ms, input_size=(H, W))
+    a.initialize(frames[0].cuda(), {"init_bbox": xywh})
+    b.initialize(frames[0].cuda(), {"init_bbox": xywh})
+    g1 = [a.track(f)["target_bbox"] for f in fr]
+    g2 = [r["target_bbox"] for r in b.track_stream(fr)]
+    assert g1 == g2 and a.frame_id == b.frame_id == 6
+
+
 def test_saturation_check_mode_counts_planted_outliers():
     """The f16x2 operand format saturates at +-65504 (csrc/common.h h2_split): no inf / NaN ever reaches an MFMA, and a context in check
     mode (uni_ctx_set_check) counts saturated operands.  (a) synthetic weights: operand buffers are scanned and nothing saturates, the

@@ -123,10 +123,15 @@ def condinst_masks(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_
 _post_ws = {}
 
 
-def postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnostic=False, precornered=False):
-    """unicorn/utils/boxes.py:33-77 for ONE image on the device (uni_postprocess): image_pred (A, 5+nc) decoded cxcywh fp32,
-    converted to corners in place (precornered=True: boxes are already xyxy).  Returns (det (M,7), anchor indices (M,) int64) or (None, None).  The only host sync is
-    the read-back of M (the output shape is data dependent)."""
+class PostTicket:
+    """uni_postprocess in flight: device buffers + the row count on its way to pinned host memory + the event that says it arrived"""
+    __slots__ = ("det", "keep", "n_dev", "n_host", "event", "A")
+
+
+def postprocess_launch(image_pred, num_classes, conf_thre, nms_thre, class_agnostic=False, precornered=False):
+    """Enqueue unicorn/utils/boxes.py:33-77 for ONE image (uni_postprocess) WITHOUT a host sync: the survivor count goes to pinned
+    host memory by an async copy and an event is recorded behind it.  `postprocess_collect(ticket)` waits for THAT event only, so
+    work enqueued later on the same stream (the next frame of a pipelined tracker loop) does not delay the read-back."""
     _need_cuda(image_pred)
     if image_pred.dtype != torch.float32 or image_pred.stride(-1) != 1:
         raise L.UnicornHipError("postprocess_image: needs a float32 (A, 5+nc) tensor with unit inner stride")
@@ -138,15 +143,34 @@ def postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnost
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1), device=dev, dtype=torch.uint8)
         _post_ws[key] = ws
-    det = torch.empty((max(A, 1), 7), device=dev, dtype=torch.float32)
-    keep = torch.empty((max(A, 1),), device=dev, dtype=torch.int32)
-    n = torch.zeros((1,), device=dev, dtype=torch.int32)
+    t = PostTicket()
+    t.A = A
+    t.det = torch.empty((max(A, 1), 7), device=dev, dtype=torch.float32)
+    t.keep = torch.empty((max(A, 1),), device=dev, dtype=torch.int32)
+    t.n_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
     L.check(L.lib().uni_postprocess(L.ptr(image_pred), A, ld, num_classes, float(conf_thre), float(nms_thre),
-                                    int(bool(class_agnostic)) | (2 if precornered else 0), A, L.ptr(det), L.ptr(keep), L.ptr(n), L.ptr(ws), ws.numel(), L.stream_ptr()), "uni_postprocess")
-    m = int(n.item())
+                                    int(bool(class_agnostic)) | (2 if precornered else 0), A, L.ptr(t.det), L.ptr(t.keep), L.ptr(t.n_dev), L.ptr(ws), ws.numel(), L.stream_ptr()), "uni_postprocess")
+    t.n_host = torch.empty((1,), dtype=torch.int32).pin_memory()
+    t.n_host.copy_(t.n_dev, non_blocking=True)
+    t.event = torch.cuda.Event()
+    t.event.record()
+    return t
+
+
+def postprocess_collect(t):
+    """-> (det (M,7), anchor indices (M,) int64) or (None, None); blocks on the ticket's own event only"""
+    t.event.synchronize()
+    m = int(t.n_host[0])
     if m == 0:
         return None, None
-    return det[:m], keep[:m].long()
+    return t.det[:m], t.keep[:m].long()
+
+
+def postprocess_image(image_pred, num_classes, conf_thre, nms_thre, class_agnostic=False, precornered=False):
+    """unicorn/utils/boxes.py:33-77 for ONE image on the device (uni_postprocess): image_pred (A, 5+nc) decoded cxcywh fp32,
+    converted to corners in place (precornered=True: boxes are already xyxy).  Returns (det (M,7), anchor indices (M,) int64) or (None, None).  The only host sync is
+    the read-back of M (the output shape is data dependent)."""
+    return postprocess_collect(postprocess_launch(image_pred, num_classes, conf_thre, nms_thre, class_agnostic, precornered))
 
 
 def letterbox(image, input_size, swap_rb=True, device=None):
@@ -216,6 +240,45 @@ def mots_overlap_free(masks):
     if m.shape[0]:
         L.check(L.lib().uni_mots_overlap_free(L.ptr(m), m.shape[0], m.shape[1], m.shape[2], L.ptr(out), L.stream_ptr()), "uni_mots_overlap_free")
     return out
+
+
+def rle_encode_launch(masks, max_runs=1 << 14):
+    """enqueue uni_rle_encode + async copies of the string lengths and characters into pinned host memory; -> ticket"""
+    _need_cuda(masks)
+    m = masks.to(torch.uint8).contiguous()
+    N, H, W = m.shape
+    if N == 0:
+        return {"N": 0}
+    max_chars = 6 * (max_runs + 1)
+    ws = torch.empty(L.lib().uni_rle_workspace_bytes(N, H, W, max_runs), device=m.device, dtype=torch.uint8)
+    chars = torch.empty((N, max_chars), device=m.device, dtype=torch.uint8)
+    lens = torch.empty((N,), device=m.device, dtype=torch.int32)
+    L.check(L.lib().uni_rle_encode(L.ptr(m), N, H, W, max_runs, max_chars, L.ptr(chars), L.ptr(lens), None, None, L.ptr(ws),
+                                   ws.numel(), L.stream_ptr()), "uni_rle_encode")
+    # the strings of real masks are short (a few hundred characters): the first `head` characters of every row travel with the
+    # lengths; a longer string (or an overflow of max_runs, length < 0) is fetched / re-encoded by rle_encode_collect
+    head = min(max_chars, 4096)
+    lens_h = torch.empty((N,), dtype=torch.int32).pin_memory()
+    chars_h = torch.empty((N, head), dtype=torch.uint8).pin_memory()
+    lens_h.copy_(lens, non_blocking=True)
+    chars_h.copy_(chars[:, :head], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return {"N": N, "m": m, "chars": chars, "lens_h": lens_h, "chars_h": chars_h, "head": head, "event": ev, "max_runs": max_runs}
+
+
+def rle_encode_collect(t):
+    if t["N"] == 0:
+        return []
+    t["event"].synchronize()
+    ln = t["lens_h"].tolist()
+    if min(ln) < 0:                          # a mask with more runs than expected: synchronous retry with larger bounds
+        return rle_encode(t["m"], max_runs=t["max_runs"] * 4)
+    if max(ln) > t["head"]:
+        host = t["chars"][:, :max(ln)].cpu().numpy()
+    else:
+        host = t["chars_h"].numpy()
+    return [host[i, :ln[i]].tobytes() for i in range(t["N"])]
 
 
 def rle_encode(masks, max_runs=1 << 14):

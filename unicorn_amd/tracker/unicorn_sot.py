@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from ..ops import corr_softmax_pv, label_map_s8, letterbox, prior_pyramid
+from ..ops import postprocess_launch
 from ..utils.boxes import postprocess
 from ..utils.timing import NoTimer
 
@@ -44,7 +45,8 @@ class UnicornSOTTrack:
         self.lbs_pre = label_map_s8(box, self.input_size[0], self.input_size[1], self.device)
         self.state = list(info["init_bbox"])
 
-    def get_det_results(self, cur):
+    def _network(self, cur):
+        """unicorn_sot.py:78-108 up to the raw head outputs (no host sync)"""
         with torch.no_grad():
             fpn, d_cur = self.model(imgs=cur, mode="backbone")
             self.t.mark("backbone+fpn")
@@ -59,22 +61,56 @@ class UnicornSOTTrack:
             outputs = self.model.head(fpn, prior_pyramid(coarse), mode="sot")
             outputs = outputs[0] if isinstance(outputs, tuple) else outputs
             self.t.mark("head")
-            det = postprocess(outputs, self.num_classes, self.confthre, self.nmsthre)[0]
-            self.t.mark("postprocess")
-            return det
+            return outputs
 
-    def track(self, image, info=None):
-        self.frame_id += 1
+    def get_det_results(self, cur):
+        outputs = self._network(cur)
+        det = postprocess(outputs, self.num_classes, self.confthre, self.nmsthre)[0]
+        self.t.mark("postprocess")
+        return det
+
+    # ---- pipelined form of track(): submit enqueues a frame (H2D, letterbox, network, uni_postprocess, async read-back of the count
+    # and of the first max_inst rows into pinned memory), collect waits for THAT frame's event only.  track() = collect(submit()).
+    def submit(self, image):
         cur, r = self._prep(image)
         self.t.mark("h2d+letterbox")
-        output = self.get_det_results(cur)
-        if output is not None:
-            output[:, 0:4:2] = output[:, 0:4:2].clamp(min=0, max=self.input_size[1])
-            output[:, 1:4:2] = output[:, 1:4:2].clamp(min=0, max=self.input_size[0])
-            output = output.cpu().numpy()[:self.max_inst]
+        outputs = self._network(cur)
+        post = postprocess_launch(outputs[0], self.num_classes, self.confthre, self.nmsthre)
+        rows = torch.empty((self.max_inst, 7), dtype=torch.float32).pin_memory()
+        rows.copy_(post.det[:self.max_inst], non_blocking=True)      # rows past the survivor count are never read
+        ev = torch.cuda.Event()
+        ev.record()
+        self.t.mark("postprocess")
+        return (post, rows, ev, r)
+
+    def collect(self, ticket):
+        post, rows, ev, r = ticket
+        self.frame_id += 1
+        ev.synchronize()
+        m = int(post.n_host[0])
+        if m > 0:
+            output = rows[:min(m, self.max_inst)].numpy().copy()
+            output[:, 0:4:2] = np.clip(output[:, 0:4:2], 0, self.input_size[1])      # unicorn_sot.py:64-65 (same fp32 values as the device clamp)
+            output[:, 1:4:2] = np.clip(output[:, 1:4:2], 0, self.input_size[0])
             b = output[:, 0:4] / r
             b[:, 2] -= b[:, 0]
             b[:, 3] -= b[:, 1]
             self.state = [int(v) for v in b[0]]
         self.t.mark("box")
         return {"target_bbox": self.state}
+
+    def track(self, image, info=None):
+        return self.collect(self.submit(image))
+
+    def track_stream(self, images):
+        """images: iterable of frames of ONE sequence -> yields track()'s result per frame with one frame of lookahead: frame t+1 is
+        enqueued before the host blocks on frame t's read-back (the SOT step of a frame depends only on the cached first frame,
+        unicorn_sot.py:78-108), so the GPU never idles behind the host.  Same boxes as per-frame track() calls."""
+        prev = None
+        for img in images:
+            tk = self.submit(img)
+            if prev is not None:
+                yield self.collect(prev)
+            prev = tk
+        if prev is not None:
+            yield self.collect(prev)
