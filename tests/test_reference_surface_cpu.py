@@ -128,3 +128,46 @@ def test_model_call_signatures_match_reference_forward():
     for k in ("imgs", "seq_dict0", "seq_dict1", "feat", "mode"):
         assert k in ref and k in ours, k
     assert ours["mode"].default == ref["mode"].default == "whole"
+
+
+def test_model_is_an_nn_module_shell():
+    """The reference's tools treat the model as a torch.nn.Module: DDP(model, device_ids=[local_rank]) (tools/track.py:193-194),
+    model.module.head (external/qdtrack/qdtrack/apis/test_omni.py:77,90), .eval() / .half().  unicorn_amd.models.Unicorn is a Module
+    shell around the HIP context: those accessors work without a GPU; torch.jit.trace (tools/export_torchscript.py:70) raises.
+    (Own process: the reference bootstrap of the other tests leaves stub modules in sys.modules that torch's DDP import chain probes.)"""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from unicorn_amd import _lib as L
+from unicorn_amd.models import Unicorn
+m = Unicorn("unicorn_track_tiny_mask")
+assert isinstance(m, torch.nn.Module) and isinstance(m.head, torch.nn.Module) and isinstance(m.head.mask_head, torch.nn.Module)
+assert [n for n, _ in m.named_modules()] == ["", "head", "head.mask_head"]
+assert m.eval() is m and not m.training and not m.head.training and m.half() is m and m.float() is m
+assert next(m.parameters()).device.type == "cpu" and list(m.state_dict()) == ["_hip_anchor"]
+try:
+    m.train()
+    raise SystemExit("train() must raise")
+except L.UnicornHipError:
+    pass
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29571")
+dist.init_process_group("gloo", rank=0, world_size=1)
+d = torch.nn.parallel.DistributedDataParallel(m)
+assert d.module is m and d.module.head is m.head and d.module.head.num_classes == 8
+dist.destroy_process_group()
+try:
+    torch.jit.trace(m, torch.zeros(1, 3, 64, 64))
+    raise SystemExit("trace must raise")
+except SystemExit:
+    raise
+except Exception:
+    pass
+print("MODULE_SURFACE_OK")
+""" % (ROOT,)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "MODULE_SURFACE_OK" in out.stdout, out.stderr[-1500:]

@@ -31,14 +31,15 @@ MODEL_CONFIGS = {
 }
 
 
-class DynamicMaskHead:
+class DynamicMaskHead(torch.nn.Module):
     """condinst/dynamic_mask_head.py: callable returning sigmoid mask scores (N,1,up_rate*H8,up_rate*W8)."""
 
     def __init__(self, up_rate):
+        super().__init__()
         self.up_rate = up_rate
         self.training = False
 
-    def __call__(self, mask_feats, mask_feat_stride, mask_head_params=None, instance_locations=None,
+    def forward(self, mask_feats, mask_feat_stride, mask_head_params=None, instance_locations=None,
                  instance_fpn_levels=None, gt_bitmasks=None, up_masks=None):
         if mask_feat_stride != 8 or up_masks is None:
             raise ValueError("DynamicMaskHead: only mask_feat_stride=8 with RAFT up_masks is supported (use_raft=True)")
@@ -46,20 +47,18 @@ class DynamicMaskHead:
                               self.up_rate, 1)
 
 
-class UnicornHead:
+class UnicornHead(torch.nn.Module):
     """unicorn_head.py:19-482 (eval branch). Owned by Unicorn; shares its context."""
 
     def __init__(self, model):
-        self._m = model
+        super().__init__()
+        object.__setattr__(self, "_m", model)          # back reference, NOT a registered submodule (the model owns the head)
         self.num_classes = model.num_classes
         self.num_classes_sot = 1
         self.decode_in_inference = True
         self.strides = [8, 16, 32]
         self.training = False
         self.hw = None
-
-    def __call__(self, xin, mask_in, labels=None, imgs=None, mode=None, **kw):
-        return self.forward(xin, mask_in, mode=mode)
 
     def _run(self, xin, mask_in, mode):
         if mode not in ("sot", "mot"):
@@ -96,7 +95,7 @@ class UnicornHead:
         self.hw = [tuple(x.shape[2:]) for x in f]
         return out, dyn, mf, um
 
-    def forward(self, xin, mask_in, mode=None):
+    def forward(self, xin, mask_in, labels=None, imgs=None, mode=None, **kw):
         return self._run(xin, mask_in, mode)[0]
 
     def decode_outputs(self, outputs, dtype=None):
@@ -116,7 +115,7 @@ class UnicornHeadMask(UnicornHead):
         self.mask_head = DynamicMaskHead(model.up_rate)
         self._levels_cache = {}
 
-    def forward(self, xin, mask_in, mode=None):
+    def forward(self, xin, mask_in, labels=None, imgs=None, mode=None, **kw):
         out, dyn, mf, um = self._run(xin, mask_in, mode)
         grids, strides = self._m._grids(self.hw, out.device)
         locations = ((grids + 0.5) * strides)[0]                               # unicorn_head_mask.py:518
@@ -129,7 +128,14 @@ class UnicornHeadMask(UnicornHead):
         return out, locations, dyn, self._levels_cache[key], mf, um
 
 
-class Unicorn:
+class Unicorn(torch.nn.Module):
+    """A `torch.nn.Module` SHELL around the HIP context: the reference's tools treat the model as a Module (`DDP(model, ...)`
+    tools/track.py:193-194, `model.module.head` external/qdtrack/qdtrack/apis/test_omni.py:77,90, `.eval()/.cuda()/.half()`), so the
+    class is one -- `.head` is a registered submodule, `.eval() / .train(False) / .modules() / next(model.parameters()).device` work,
+    and one 1-element `_hip_anchor` parameter (untouched by the forward) lets `DistributedDataParallel` wrap it.  The weights
+    themselves live re-packed inside the context (csrc/engine.hip), not as torch parameters: `state_dict()` returns the anchor only,
+    `load_state_dict` takes the reference checkpoint namespace.  `torch.jit.trace` cannot see through the C-ABI calls and raises."""
+
     def __init__(self, name_or_cfg="unicorn_track_tiny", device=None, precision="f16x2"):
         """precision (operand format of every dense contraction; accumulation, residual stream and statistics are fp32):
           "f16x2"  (default) fp32-equivalent: operands split into hi + lo f16 halves, 3 f16 MFMAs per product (22 operand bits).
@@ -140,9 +146,11 @@ class Unicorn:
           "fp32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain; 16x the bf16 MFMA cost.
           "bf16"   bf16 operands, 1 MFMA per product; fastest, embedding cosine still within 1e-4 but box IoU is NOT
                    (8 operand bits; profiles/r02_precision_budget.json)."""
+        super().__init__()
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (sorted(PRECISIONS),))
         self.precision = precision
+        self._hip_anchor = torch.nn.Parameter(torch.zeros(1))
         cfg = dict(MODEL_CONFIGS[name_or_cfg]) if isinstance(name_or_cfg, str) else dict(name_or_cfg)
         self.cfg_name = name_or_cfg if isinstance(name_or_cfg, str) else "custom"
         self.dims, self.depths = tuple(cfg["dims"]), tuple(cfg["depths"])
@@ -162,7 +170,7 @@ class Unicorn:
         if device is not None:
             self.cuda(device)
 
-    # ---------------------------------------------------------------- nn.Module-like surface
+    # ---------------------------------------------------------------- nn.Module surface (overrides: the weights are not torch tensors)
     def cuda(self, device=None):
         if not torch.cuda.is_available():
             raise L.UnicornHipError("unicorn_amd needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
@@ -172,6 +180,7 @@ class Unicorn:
         if self._ctx is not None and self._device is not None and self._device.index != idx:
             raise L.UnicornHipError("model already bound to %s" % self._device)
         self._device = torch.device("cuda", idx)
+        self._hip_anchor.data = self._hip_anchor.data.to(self._device)
         if self._ctx is None:
             c = L.ModelCfg()
             c.dims[:] = self.dims
@@ -188,17 +197,18 @@ class Unicorn:
                 self._load(sd)
         return self
 
-    def to(self, device):
+    def to(self, device=None, *a, **k):
+        if device is None or isinstance(device, torch.dtype):      # .to(dtype): the operand format is fixed by `precision`
+            return self
         return self.cuda(device)
-
-    def eval(self):
-        self.training = False
-        return self
 
     def train(self, mode=True):
         if mode:
             raise L.UnicornHipError("unicorn_amd implements the inference path only")
-        return self
+        return super().train(False)                                 # .eval() == .train(False)
+
+    def state_dict(self, *a, **k):
+        return super().state_dict(*a, **k)                          # the anchor only; the packed weights are device-side and immutable
 
     def half(self):
         # tools/track.py --fp16 calls model.half() and feeds half images (mot_evaluator.py:126-128): the operand format of the HIP
@@ -299,10 +309,10 @@ class Unicorn:
         return self._pos_cache[key]
 
     # ---------------------------------------------------------------- forward modes
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
-
     def forward(self, imgs=None, run_fpn=True, seq_dict0=None, seq_dict1=None, feat=None, mode="whole", **unused):
+        if torch.jit.is_tracing():
+            raise L.UnicornHipError("torch.jit.trace cannot record the C-ABI calls of unicorn_amd (tools/export_torchscript.py:70); "
+                                    "use head.decode_in_inference = False for the raw export rows instead")
         if mode == "backbone":
             return self.forward_backbone(imgs, run_fpn)
         elif mode == "interaction":
