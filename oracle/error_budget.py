@@ -140,6 +140,23 @@ def metrics(o, ref, cfg):
     return m
 
 
+def trained_like(cfg, seed):
+    """Synthetic weights shaped like a TRAINED detector's (no checkpoint exists offline): the synthetic draw of oracle/synth.py with
+    (a) obj / cls prediction biases planted at logit(0.5) + N(0, 1) per level instead of -4.5 (scores spread over 0.05 - 0.95, so the
+    top-500 anchors are confident detections, not the tail of a 1e-4 distribution), (b) the last prediction layers (reg / obj / cls
+    preds) damped x 0.25 (a trained regressor's output varies smoothly with its input; an undamped random one amplifies feature noise),
+    (c) a different seed per draw."""
+    P = synth.synth_state_dict(cfg, seed=100 + seed)
+    g = torch.Generator().manual_seed(seed)
+    for k in list(P):
+        if k.startswith("head.") and any(t in k for t in ("cls_preds", "obj_preds", "reg_preds")):
+            if k.endswith("weight"):
+                P[k] = P[k] * 0.25
+            elif "reg_preds" not in k:
+                P[k] = torch.randn(P[k].shape, generator=g)
+    return P
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="unicorn_track_tiny")
@@ -147,6 +164,10 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true", help="uniform policies only")
+    ap.add_argument("--ensemble", type=int, default=0, metavar="N",
+                    help="N weight draws of a TRAINED-LIKE ensemble instead of the single synthetic draw (VERDICT r03 weak #3): head biases "
+                         "planted so that obj * cls scores are O(0.1 - 0.9) instead of ~1e-4, regression / prediction weights damped so the "
+                         "top anchors carry boxes of the init-box scale, different seeds; uniform policies only")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install()
@@ -154,6 +175,27 @@ def main():
     P = synth.synth_state_dict(cfg)
     H, W = args.size
     frames, box = synth.synth_clip(H, W, 2, seed=1)
+    if args.ensemble:
+        rows = {}
+        for seed in range(args.ensemble):
+            P = trained_like(cfg, seed)
+            frames, box = synth.synth_clip(H, W, 2, seed=1 + seed)
+            ref = run(P, cfg, frames, box, Policy("fp32"))
+            ho = ref["head"][0] if cfg.mask else ref["head"]
+            sc = (ho[0, :, 4] * ho[0, :, 5]).sort(descending=True)[0]
+            print("seed %d: top score %.3f, 500th %.3f" % (seed, float(sc[0]), float(sc[499])), flush=True)
+            for f in ("bf16", "f16", "bf16x2", "f16x2"):
+                m = metrics(run(P, cfg, frames, box, Policy(f)), ref, cfg)
+                rows["seed%d all=%s" % (seed, f)] = m
+                print("seed", seed, f, json.dumps({k: round(v, 6) for k, v in m.items() if k in ("iou_min", "iou_mean", "embed_cos_min", "fpn0", "score_rel")}), flush=True)
+        summ = {f: {"iou_min": min(rows["seed%d all=%s" % (s_, f)]["iou_min"] for s_ in range(args.ensemble)),
+                    "iou_mean_min": min(rows["seed%d all=%s" % (s_, f)]["iou_mean"] for s_ in range(args.ensemble))}
+                for f in ("bf16", "f16", "bf16x2", "f16x2")}
+        print("summary", json.dumps(summ))
+        if args.out:
+            json.dump({"model": args.model, "size": [H, W], "ensemble": args.ensemble, "what": trained_like.__doc__, "summary": summ, "rows": rows},
+                      open(args.out, "w"), indent=1)
+        return
     ref = run(P, cfg, frames, box, Policy("fp32"))
     rows = {}
 
