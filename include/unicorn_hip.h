@@ -232,11 +232,10 @@ int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta
                   uint16_t* outB, uni_stream_t stream);
 int uni_dwconv7_ln(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta,
                    float eps, int H, int W, int C, uint16_t* out_bf16, uni_stream_t stream);
-/* The same for B stacked (H,W,C) maps and any operand format: fmt 0 = bf16 rows, 1 = fp32 rows, 2 = f16x2 rows ([8 hi][8 lo] groups).
- * variant 0 = the engine's choice, 1 = the rolling-window kernel (csrc/dwln_roll.hip; error if the map is too small for it),
- * 2 = never the rolling-window kernel (tests hold both to the same reference).  convnext.py:30-33,47-49. */
+/* The same for B stacked (H,W,C) maps and any operand format (what the engine calls per ConvNeXt block): fmt 0 = bf16 rows, 1 = fp32
+ * rows, 2 = f16x2 rows ([8 hi][8 lo] groups).  convnext.py:30-33,47-49. */
 int uni_dwconv7_ln_ex(const float* x_nhwc, const float* w49c, const float* bias, const float* gamma, const float* beta, float eps,
-                      int B, int H, int W, int C, void* out, int fmt, int variant, uni_stream_t stream);
+                      int B, int H, int W, int C, void* out, int fmt, uni_stream_t stream);
 /* The engine's sampler of the ref <-> cur interaction (csrc/msda.hip msda_wave_kernel: one wave per (token, head), shuffle reductions):
  * Unicorn's fixed geometry -- 8 heads x 32 channels, 2 levels = reference / current frame of identical (h, w), 4 points -- with
  * MSDeformAttn.forward's softmax over the 8 logits and loc = ref + off / (W, H) fused in (ms_deform_attn.py:98-105,

@@ -271,12 +271,12 @@ def _dwln_decode(out, fmt, M, C_):
 
 
 @pytest.mark.parametrize("fmt", [2, 1, 0])
-@pytest.mark.parametrize("shape", [(768, 6, 49, 83), (192, 2, 101, 163), (256, 3, 57, 90), (384, 4, 50, 81), (512, 5, 33, 70),
-                                   (768, 16, 50, 80)])
-def test_dwconv7_ln_rolling_window(L, shape, fmt):
-    """csrc/dwln_roll.hip (rolling-window kernel: every input row loaded once per 4-px column strip, seven rotating accumulator sets)
-    against torch's depthwise conv + LayerNorm, for every operand format, B stacked maps, widths that are no multiple of 4 and heights
-    that are no multiple of the column chunk; and against the 2 / 4-row kernels it replaces (variant 2)."""
+@pytest.mark.parametrize("shape", [(768, 6, 49, 83), (192, 2, 101, 163), (256, 3, 57, 90), (384, 4, 50, 81), (512, 5, 33, 70), (96, 3, 20, 24),
+                                   (768, 1, 10, 10)])
+def test_dwconv7_ln_batched_all_formats(L, shape, fmt):
+    """uni_dwconv7_ln_ex = the call the engine makes per ConvNeXt block: B stacked maps, every operand format (bf16 / fp32 / f16x2 rows),
+    widths that are no multiple of the 8-px strips, odd heights (2- and 4-row kernels), against torch's depthwise conv + LayerNorm;
+    samples must not leak into each other (zero padding between stacked maps)."""
     C_, B, H, W = shape
     g = torch.Generator().manual_seed(C_ + H + B)
     x = torch.randn(B, C_, H, W, generator=g)
@@ -287,26 +287,12 @@ def test_dwconv7_ln_rolling_window(L, shape, fmt):
     wt = w.reshape(C_, 49).t().contiguous().cuda()
     bd, gd, bed = b.cuda(), ga.cuda(), be.cuda()
     M = B * H * W
-    outs = []
-    for variant in (1, 2):
-        out = torch.full((M, C_), 7.0, device="cuda", dtype=torch.bfloat16 if fmt == 0 else torch.float32)
-        L.check(L.lib().uni_dwconv7_ln_ex(L.ptr(xn), L.ptr(wt), L.ptr(bd), L.ptr(gd), L.ptr(bed), 1e-6, B, H, W, C_, L.ptr(out), fmt, variant,
-                                          L.stream_ptr()), "dwln_ex")
-        torch.cuda.synchronize()
-        outs.append(_dwln_decode(out, fmt, M, C_))
-    tol = 8e-3 if fmt == 0 else 2e-5
-    scale = max(1.0, exp.abs().max().item())
-    for o in outs:
-        assert (o - exp).abs().max().item() < tol * scale
-    # the column strips of different samples / chunks must not leak into each other: the first and the last sample alone agree too
-    assert (outs[0][:H * W] - exp[:H * W]).abs().max().item() < tol * scale
-
-
-def test_dwconv7_ln_rolling_window_refuses_small_maps(L):
-    x = torch.zeros(1, 10, 10, 768, device="cuda")
-    w, v = torch.zeros(49, 768, device="cuda"), torch.zeros(768, device="cuda")
-    out = torch.zeros(100, 768, device="cuda")
-    assert L.lib().uni_dwconv7_ln_ex(L.ptr(x), L.ptr(w), L.ptr(v), L.ptr(v), L.ptr(v), 1e-6, 1, 10, 10, 768, L.ptr(out), 1, 1, L.stream_ptr()) != 0
+    out = torch.full((M, C_), 7.0, device="cuda", dtype=torch.bfloat16 if fmt == 0 else torch.float32)
+    L.check(L.lib().uni_dwconv7_ln_ex(L.ptr(xn), L.ptr(wt), L.ptr(bd), L.ptr(gd), L.ptr(bed), 1e-6, B, H, W, C_, L.ptr(out), fmt, L.stream_ptr()), "dwln_ex")
+    torch.cuda.synchronize()
+    o = _dwln_decode(out, fmt, M, C_)
+    tol = 1.6e-2 if fmt == 0 else 2e-5            # bf16: half an ulp of the largest output
+    assert (o - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item())
 
 
 @pytest.mark.parametrize("C_,G,act", [(256, 16, 3), (192, 16, 3), (48, 16, 3), (256, 32, 0), (128, 16, 1)])

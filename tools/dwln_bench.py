@@ -1,6 +1,5 @@
-"""The fused depthwise 7x7 + LayerNorm kernels alone on the ConvNeXt / head maps of the large model at B frames, f16x2 operand output
-(the engine's format): variant 1 = rolling-window kernel (csrc/dwln_roll.hip), 2 = the 2 / 4-row kernels of norm.hip, 0 = the engine's choice.
-UNI_DW_NOLDSW=1 selects the non-persistent kernels, UNI_DW_PX the pixel tiling of variant 2."""
+"""The fused depthwise 7x7 + LayerNorm kernels alone on the ConvNeXt / head maps of the large model at B frames, in the engine's operand
+format (FMT: 2 = f16x2 default, 0 = bf16, 1 = fp32).  UNI_DW_NOLDSW=1 selects the non-persistent kernels, UNI_DW_PX / UNI_DW_ROWS the tiling."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,19 +12,15 @@ for (C, H, W) in [(768, 50, 80), (192, 200, 320), (384, 100, 160), (256, 100, 16
     w = torch.randn(49, C, device="cuda") * 0.1
     b, g, be = torch.randn(C, device="cuda"), torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
     out = torch.empty((B * H * W, C), device="cuda", dtype=torch.bfloat16 if FMT == 0 else torch.float32)
-    for variant in (1, 2, 0):
-        def run():
-            return lib.uni_dwconv7_ln_ex(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(g), L.ptr(be), 1e-6, B, H, W, C, L.ptr(out), FMT, variant, L.stream_ptr())
-        if run() != 0:
-            print("C=%4d %3dx%3d B=%d variant %d: not covered" % (C, H, W, B, variant))
-            continue
-        best = 1e9
-        for rep in range(3):
-            for _ in range(3): run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10): run()
-            e1.record(); torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / 10)
-        eb = 6 if FMT == 0 else 8
-        print("C=%4d %3dx%3d B=%d variant %d: %7.1f us  %.2f TB/s algorithmic (%d B/elem)" % (C, H, W, B, variant, best * 1e3, B * H * W * C * eb / best / 1e9, eb))
+    def run():
+        L.check(lib.uni_dwconv7_ln_ex(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(g), L.ptr(be), 1e-6, B, H, W, C, L.ptr(out), FMT, L.stream_ptr()), "dwln_ex")
+    best = 1e9
+    for rep in range(3):
+        for _ in range(3): run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 10)
+    eb = 6 if FMT == 0 else 8
+    print("C=%4d %3dx%3d B=%d: %7.1f us  %.2f TB/s algorithmic (%d B/elem)" % (C, H, W, B, best * 1e3, B * H * W * C * eb / best / 1e9, eb))

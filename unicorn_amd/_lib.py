@@ -67,7 +67,7 @@ PROTOS = {
     "uni_mlp_fused": (c_i, [c_f, c_i, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p]),
     "uni_layernorm": (c_i, [c_f, c_i, c_f, c_f, C.c_float, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_dwconv7_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_f, C.c_void_p]),
-    "uni_dwconv7_ln_ex": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_f, c_i, c_i, C.c_void_p]),
+    "uni_dwconv7_ln_ex": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_f, c_i, C.c_void_p]),
     "uni_msda_tokens": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f, C.c_void_p]),
     "uni_groupnorm_act": (c_i, [c_f, c_f, c_f, c_f, C.c_float, c_i, c_i, c_i, c_i, c_f, c_f, C.c_void_p]),
     "uni_stem": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, C.c_void_p]),

@@ -321,12 +321,12 @@ int uni_dwconv7_ln(const float* x, const float* w49c, const float* bias, const f
     API(launch_dwconv7_ln(d, S(stream)));
 }
 int uni_dwconv7_ln_ex(const float* x, const float* w49c, const float* bias, const float* gamma, const float* beta, float eps, int B, int H,
-                      int W, int C, void* out, int fmt, int variant, uni_stream_t stream) {
+                      int W, int C, void* out, int fmt, uni_stream_t stream) {
     UNI_REQUIRE(x && w49c && bias && gamma && beta && out, "dwconv7_ln_ex: NULL argument");
-    UNI_REQUIRE(B > 0 && H > 0 && W > 0 && fmt >= 0 && fmt <= 2 && variant >= 0 && variant <= 2, "dwconv7_ln_ex: B=%d H=%d W=%d fmt=%d variant=%d", B, H, W, fmt, variant);
+    UNI_REQUIRE(B > 0 && H > 0 && W > 0 && fmt >= 0 && fmt <= 2, "dwconv7_ln_ex: B=%d H=%d W=%d fmt=%d", B, H, W, fmt);
     DwLnArgs d;
     d.x = x; d.w = w49c; d.bias = bias; d.gamma = gamma; d.beta = beta; d.eps = eps; d.H = H; d.W = W; d.C = C; d.B = B;
-    d.out = reinterpret_cast<bf16*>(out); d.b32 = fmt; d.variant = variant;
+    d.out = reinterpret_cast<bf16*>(out); d.b32 = fmt;
     API(launch_dwconv7_ln(d, S(stream)));
 }
 int uni_msda_tokens(const float* value, const float* offaw, int ldo, int B, int h, int w, float* out, uni_stream_t stream) {

@@ -111,13 +111,8 @@ struct DwLnArgs {
     int H = 0, W = 0, C = 0, B = 1;            // B images of (H,W,C) stacked
     bf16* out = nullptr;
     int b32 = 0;
-    int variant = 0;                          // tests / tools: 0 = heuristic, 1 = rolling-window kernel or error, 2 = never the rolling-window kernel
 };
 int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s);
-// dwln_roll.hip: rolling-window variant for the big maps (every input row loaded once per 4-px column strip); plan returns 0 when the map
-// is too small for it, else the rows per column chunk.  UNI_NO_DW_ROLL = A/B switch (launch_dwconv7_ln then takes the 2 / 4-row kernels).
-int dwconv7_lnr_plan(int B, int H, int W, int C, int* R_out, int* nchunks_out);
-int launch_dwconv7_lnr(const DwLnArgs& a, int R, int nchunks, hipStream_t s);
 
 // stem: conv4x4/s4 (3->C) + bias + LN_cf: NCHW fp32 image -> fp32 NHWC
 struct StemArgs {

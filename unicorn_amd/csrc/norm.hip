@@ -696,14 +696,6 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     int px = n8 >= 150000L ? 16 : n8 >= 70000L ? 8 : 4;
     if (env) px = atoi(env);
     if (px == 16) {
-        // big maps: the rolling-window kernel (dwln_roll.hip) loads every input row once per 4-px column strip (~3 input float4s per output
-        // float4 instead of 7 / 4.4 here)
-        static const bool no_roll = getenv("UNI_NO_DW_ROLL") != nullptr;
-        int rollR = 0, rollN = 0;
-        if (!no_roll && a.variant != 2 && dwconv7_lnr_plan(nb, a.H, a.W, a.C, &rollR, &rollN)) return launch_dwconv7_lnr(a, rollR, rollN, s);
-    }
-    if (a.variant == 1) { uni_set_error("dwconv7_ln: the rolling-window kernel does not cover B=%d H=%d W=%d C=%d", nb, a.H, a.W, a.C); return -1; }
-    if (px == 16) {
         const int spr = cdiv(a.W, 8), nstrips = spr * ((a.H + 1) / 2) * nb;
         // persistent variant (row descriptors, register double buffer, weights in LDS): C a multiple of 256, 49 C floats + scratch
         // within 160 KB, at least two rounds of work for 256 CUs and a row shorter than 2 GiB / 4
