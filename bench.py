@@ -185,6 +185,64 @@ def make_gather(rank, stat, group=None):
     return gather
 
 
+class GpuSensor:
+    """Shader clock (hwmon freq1_input) and board power (power1_input) of THIS process's GPU, sampled from sysfs by a background thread
+    while a timed region runs: the f16x2 GEMMs are power-limited on random operands, so the roofline block also
+    reports the achieved rate against the MFMA peak at the clock the chip actually sustained."""
+
+    def __init__(self, dev_index, period=0.005):
+        import glob
+        import threading
+        self.paths, self.samples, self.period = None, [], period
+        self._stop, self._th = threading.Event(), None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)) != want:
+                    continue
+                for h in glob.glob(d + "/hwmon/hwmon*"):
+                    if os.path.exists(h + "/freq1_input") and os.path.exists(h + "/power1_input"):
+                        self.paths = (h + "/freq1_input", h + "/power1_input", h + "/power1_cap")
+        except Exception:                           # noqa: BLE001 -- no sensor, no block
+            self.paths = None
+
+    def __enter__(self):
+        import threading
+        self.samples = []
+        self._stop.clear()
+        if self.paths:
+            def loop():
+                while not self._stop.is_set():
+                    try:
+                        self.samples.append((int(open(self.paths[0]).read()) / 1e6, int(open(self.paths[1]).read()) / 1e6))
+                    except Exception:               # noqa: BLE001
+                        pass
+                    time.sleep(self.period)
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._th is not None:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        f = sorted(x[0] for x in self.samples)
+        w = sorted(x[1] for x in self.samples)
+        cap = None
+        try:
+            cap = int(open(self.paths[2]).read()) / 1e6
+        except Exception:                           # noqa: BLE001
+            pass
+        return {"sclk_mhz_mean": round(sum(f) / len(f), 1), "sclk_mhz_min": f[0], "sclk_mhz_max": f[-1], "power_w_mean": round(sum(w) / len(w), 1),
+                "power_w_max": w[-1], "power_cap_w": cap, "samples": len(f), "source": "sysfs hwmon freq1_input / power1_input of this GPU"}
+
+
 def box_iou_pairs(a, b):
     import torch
     ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
@@ -427,7 +485,10 @@ def main():
 
         def gather(streams):
             return gather_rows(streams if not errs else [_Empty])
-    dt, own_dt, _ = timed([main_s] if main_s is not None else [], args.steps, args.warmup, barrier, gather, max(1, args.gather_every), errs)
+    sensor = GpuSensor(local_rank)
+    with sensor:
+        dt, own_dt, _ = timed([main_s] if main_s is not None else [], args.steps, args.warmup, barrier, gather, max(1, args.gather_every), errs)
+    clocks = sensor.summary()
     fps_frames = args.steps * main_s.frames_per_step() if (main_s is not None and not errs) else 0
     per_rank, rank_errors = None, None
     if dist is not None:
@@ -530,6 +591,9 @@ def main():
                 # the same achieved rate against the other two peaks SURVEY.md 8(d) names: the raw dense 16-bit MFMA peak (what a 1-MFMA
                 # bf16 product would be priced at) and the exact-fp32 MFMA peak (what the fp32 reference arithmetic would cost on MFMA)
                 "frac_vs_f16_peak": round(ach / 2500.0, 4), "frac_vs_fp32_mfma": round(ach / 157.3, 3),
+                # sustained shader clock / board power during the timed loop (sysfs) and the same rate against the MFMA peak AT THAT CLOCK
+                "clocks": clocks,
+                "frac_vs_peak_at_sustained_clock": round(ach / (peak * clocks["sclk_mhz_mean"] / 2400.0), 4) if clocks else None,
                 "traffic": traffic, "traffic_source": tsrc, "traffic_measured_in_run": False,
                 "traffic_note": "HBM bytes per launch replayed from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/), not collected in this run",
                 "peak_note": "dense 16-bit MFMA 2500 TFLOP/s / %d MFMAs per fp32-equivalent product" % mfma_per_product if mfma_per_product > 1 else "dense MFMA peak of the dtype",
@@ -579,11 +643,13 @@ def main():
                 main_s.sot_batch(main_s.frames[1])
             torch.cuda.synchronize()
             lats = []
-            for i in range(20):
-                t1 = time.perf_counter()
-                main_s.sot_batch(main_s.frames[1 + i % 4])
-                torch.cuda.synchronize()
-                lats.append(time.perf_counter() - t1)
+            sens1 = GpuSensor(local_rank)
+            with sens1:
+                for i in range(20):
+                    t1 = time.perf_counter()
+                    main_s.sot_batch(main_s.frames[1 + i % 4])
+                    torch.cuda.synchronize()
+                    lats.append(time.perf_counter() - t1)
             buf1 = (C.c_double * 16)()
             L.check(L.lib().uni_prof_begin(main_s.model._ctx), "prof_begin")
             for i in range(3):
@@ -609,7 +675,7 @@ def main():
                                "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2),
                                "note": "kernel time by HIP events with the head levels serialised (profiling mode); whole-call fp32-equivalent rate = "
                                        "%.1f TFLOP/s" % (g_work / lat / 1e12)},
-                  "hbm": hb1, "misc_ms_per_frame": round(v1[12] / 3, 4)}
+                  "hbm": hb1, "misc_ms_per_frame": round(v1[12] / 3, 4), "clocks": sens1.summary()}
 
     # ---------------- CPU baseline (the oracle = port of the reference, host cores, bounded sample) + in-run parity ----------------
     cpu, parity = None, None
@@ -740,6 +806,11 @@ def main():
                 configs["sot_track_raw_1080p"] = staged(lambda i: trk.track(raw[1 + i % 3]), trk.t,
                                                         stream=lambda k: sum(1 for _ in trk.track_stream(raw[1 + j % 3] for j in range(k))),
                                                         set_timer=lambda t_: setattr(trk, "t", t_))
+                torch.cuda.synchronize()
+                t1_ = time.perf_counter()
+                n4 = sum(1 for _ in trk.track_stream((raw[1 + j % 3] for j in range(48)), batch=4))
+                torch.cuda.synchronize()
+                configs["sot_track_raw_1080p"]["ms_per_frame_stream_batch4"] = round(1e3 * (time.perf_counter() - t1_) / n4, 3)
                 configs["sot_track_raw_1080p"]["note"] = ("UnicornSOTTrack.track / track_stream per frame: pinned uint8 1080p -> H2D -> uni_letterbox -> backbone+FPN -> interaction -> "
                                                           "2 x upsample -> correlation -> head -> uni_postprocess (conf thr set for ~200 candidates) -> box")
             # (b) evaluate_omni loop, one frame per call

@@ -724,6 +724,10 @@ def test_omni_stream_pipelined_equals_per_frame():
     g1 = [a.track(f)["target_bbox"] for f in fr]
     g2 = [r["target_bbox"] for r in b.track_stream(fr)]
     assert all(abs(x - y) <= 1 for p_, q_ in zip(g1, g2) for x, y in zip(p_, q_)) and a.frame_id == b.frame_id == 6
+    c = UnicornSOTTrack(ms, input_size=(H, W))
+    c.initialize(frames[0].cuda(), {"init_bbox": xywh})
+    g3 = [r["target_bbox"] for r in c.track_stream(fr, batch=4)]        # passes of 4 + 2 frames
+    assert len(g3) == 6 and all(abs(x - y) <= 1 for p_, q_ in zip(g1, g3) for x, y in zip(p_, q_)) and c.frame_id == 6
 
 
 def test_saturation_check_mode_counts_planted_outliers():

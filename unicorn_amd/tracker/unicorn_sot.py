@@ -46,19 +46,22 @@ class UnicornSOTTrack:
         self.state = list(info["init_bbox"])
 
     def _network(self, cur):
-        """unicorn_sot.py:78-108 up to the raw head outputs (no host sync)"""
+        """unicorn_sot.py:78-108 up to the raw head outputs (no host sync) for B >= 1 current frames against the cached first frame
+        (the SOT step of a frame depends on nothing but that frame, so consecutive frames may share one pass)"""
         with torch.no_grad():
+            B = cur.shape[0]
             fpn, d_cur = self.model(imgs=cur, mode="backbone")
             self.t.mark("backbone+fpn")
             f_pre, f_cur = self.model(seq_dict0=self.out_dict_pre, seq_dict1=d_cur, mode="interaction")
             e_pre = self.model(feat=f_pre, mode="upsample")
             e_cur = self.model(feat=f_cur, mode="upsample")
             self.t.mark("interaction+upsample")
-            pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), self.lbs_pre,
-                                   precision=0 if getattr(self.model, "precision", "f16x2") == "fp32" else 2)
-            coarse = pred.view(1, -1, self.dh, self.dw)
+            prec = 0 if getattr(self.model, "precision", "f16x2") == "fp32" else 2
+            pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), self.lbs_pre, precision=prec) for b in range(B)], 0)
+            coarse = pred.view(1, B, self.dh, self.dw)
             self.t.mark("correlation")
-            outputs = self.model.head(fpn, prior_pyramid(coarse), mode="sot")
+            pri = tuple(t.transpose(0, 1).contiguous() for t in prior_pyramid(coarse)) if B > 1 else prior_pyramid(coarse)
+            outputs = self.model.head(fpn, pri, mode="sot")
             outputs = outputs[0] if isinstance(outputs, tuple) else outputs
             self.t.mark("head")
             return outputs
@@ -72,16 +75,26 @@ class UnicornSOTTrack:
     # ---- pipelined form of track(): submit enqueues a frame (H2D, letterbox, network, uni_postprocess, async read-back of the count
     # and of the first max_inst rows into pinned memory), collect waits for THAT frame's event only.  track() = collect(submit()).
     def submit(self, image):
-        cur, r = self._prep(image)
+        return self.submit_batch([image])[0]
+
+    def submit_batch(self, images):
+        """enqueue B consecutive frames as ONE pass (one letterbox per frame, one network call, one uni_postprocess per frame, async
+        read-back of the survivor counts and of the first max_inst rows into pinned memory) -> one ticket per frame"""
+        prepped = [self._prep(im) for im in images]
         self.t.mark("h2d+letterbox")
+        cur = prepped[0][0] if len(prepped) == 1 else torch.cat([c for c, _ in prepped], 0)
         outputs = self._network(cur)
-        post = postprocess_launch(outputs[0], self.num_classes, self.confthre, self.nmsthre)
-        rows = torch.empty((self.max_inst, 7), dtype=torch.float32).pin_memory()
-        rows.copy_(post.det[:self.max_inst], non_blocking=True)      # rows past the survivor count are never read
+        posts, rows = [], []
+        for b in range(len(prepped)):
+            post = postprocess_launch(outputs[b], self.num_classes, self.confthre, self.nmsthre)
+            rw = torch.empty((self.max_inst, 7), dtype=torch.float32).pin_memory()
+            rw.copy_(post.det[:self.max_inst], non_blocking=True)      # rows past the survivor count are never read
+            posts.append(post)
+            rows.append(rw)
         ev = torch.cuda.Event()
         ev.record()
         self.t.mark("postprocess")
-        return (post, rows, ev, r)
+        return [(posts[b], rows[b], ev, prepped[b][1]) for b in range(len(prepped))]
 
     def collect(self, ticket):
         post, rows, ev, r = ticket
@@ -102,15 +115,32 @@ class UnicornSOTTrack:
     def track(self, image, info=None):
         return self.collect(self.submit(image))
 
-    def track_stream(self, images):
-        """images: iterable of frames of ONE sequence -> yields track()'s result per frame with one frame of lookahead: frame t+1 is
-        enqueued before the host blocks on frame t's read-back (the SOT step of a frame depends only on the cached first frame,
-        unicorn_sot.py:78-108), so the GPU never idles behind the host.  Same boxes as per-frame track() calls."""
-        prev = None
+    def track_stream(self, images, batch=1):
+        """images: iterable of frames of ONE sequence -> yields track()'s result per frame, in order.  The next pass is enqueued before
+        the host blocks on the read-back of the previous one (the SOT step of a frame depends only on the cached first frame,
+        unicorn_sot.py:78-108), so the GPU never idles behind the host.  batch > 1 (offline evaluation: throughput over latency) runs
+        `batch` consecutive frames per pass -- the time-batched step bench.py's headline measures.  Same boxes as per-frame track() calls."""
+        prev, buf = None, []
+
+        def flush():
+            nonlocal prev, buf
+            tks = self.submit_batch(buf)
+            buf = []
+            out = prev
+            prev = tks
+            return out
         for img in images:
-            tk = self.submit(img)
-            if prev is not None:
-                yield self.collect(prev)
-            prev = tk
+            buf.append(img)
+            if len(buf) == batch:
+                done = flush()
+                if done is not None:
+                    for tk in done:
+                        yield self.collect(tk)
+        if buf:
+            done = flush()
+            if done is not None:
+                for tk in done:
+                    yield self.collect(tk)
         if prev is not None:
-            yield self.collect(prev)
+            for tk in prev:
+                yield self.collect(tk)
