@@ -694,7 +694,7 @@ def test_omni_stream_pipelined_equals_per_frame():
         assert torch.equal(i1, i1.sort()[0])                          # ascending track ids (mot_evaluator.py:1052-1055)
     # a high threshold on the score empties some frames: the loop must survive frames without detections (result (None, None))
     hi = mk()
-    hi.confthre = float(sc[0]) * 1.5
+    hi.confthre = 0.99                                               # synthetic scores are << 1: no frame has a detection
     with torch.no_grad():
         assert all(r[0] == (None, None) for r in hi.run_stream(fr[:3], info)) and hi.pre_dict is None and hi.frame_id == 3
     del m

@@ -23,9 +23,11 @@ SHAPES = [
     ("1x1 16000x1024x256", 16000, 1, 256, 1024, 1, 0, 0, 0), ("1x1 4000x768x768", 4000, 1, 768, 768, 1, 0, 0, 0),
     ("1x1 16000x192x192", 16000, 1, 192, 192, 1, 0, 0, 0), ("1x1 4000x256x1024", 4000, 1, 1024, 256, 1, 0, 0, 0),
 ]
-CFGS = [0, 188, 22, 11, 322, 323, 332, 331]
-SPLITS = [1, 2, 3, 4]
-SPLIT_CFGS = (188, 22, 323, 331)
+CFGS = [int(v) for v in os.environ.get("CFGS", "0,188,22,11,322,323,332,331").split(",")]
+SPLITS = [int(v) for v in os.environ.get("SPLITS", "1,2,3,4").split(",")]
+SPLIT_CFGS = tuple(int(v) for v in os.environ.get("SPLIT_CFGS", "188,22,323,331").split(","))
+if os.environ.get("ONLY"):
+    SHAPES = [s_ for s_ in SHAPES if any(t in s_[0] for t in os.environ["ONLY"].split(","))]
 print("%-28s | " % "shape" + " ".join("%9s" % ("c%d/s%d" % (c, sk)) for c in CFGS for sk in (SPLITS if c in SPLIT_CFGS else [1])))
 for name, Hin, Win, Cin, N, k, act, use_res, use_B in SHAPES:
     pad = (k - 1) // 2
