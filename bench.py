@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--rccl-probe", action="store_true", help=argparse.SUPPRESS)      # child process of init_dist(): RCCL rendezvous + collectives, then exit
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline AND in-run parity)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (no modes / configs sub-results)")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (clean per-kernel averages under rocprofv3)")
     ap.add_argument("--with-bf16", action="store_true", help="also time the bf16 operand mode (1 MFMA per product).  Retired from the default line: it "
                     "misses the box-IoU bar with the synthetic AND the trained-like weight ensembles (profiles/r04_precision_budget_trained_like_*.json)")
     ap.add_argument("--launch-check", action="store_true", help="only rendezvous (gloo on CPU, RCCL on GPUs) and report the world size")
@@ -638,7 +639,7 @@ def main():
     # ---------------- single-frame leg: ONE (1,3,H,W) frame per call, host-synchronised per frame = the reference drivers' call pattern
     # (external/lib/test/tracker/unicorn_sot.py:57-76), with its own roofline block ----------------
     single = None
-    if rank == 0 and task == "sot":
+    if rank == 0 and task == "sot" and not args.no_single_frame:
         import ctypes as C
         with torch.no_grad():
             for _ in range(3):

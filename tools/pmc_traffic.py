@@ -23,6 +23,7 @@ def rows_of(d):
 
 
 out = {}
+parts = collections.defaultdict(dict)     # per GEMM kernel instantiation: where the class average comes from
 for tag, d in (("fetch", sys.argv[1]), ("write", sys.argv[2])):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for kname, cname, val in rows_of(d):
@@ -34,7 +35,15 @@ for tag, d in (("fetch", sys.argv[1]), ("write", sys.argv[2])):
         cls = "gemm_bf16_kernel" if "gemm_bf16" in name else ("gemm_h2_kernel" if ("gemm_h2" in name or "mlp_fused" in name) else name[:40])
         acc[cls][0] += val * 1024.0 * (2.0 if tag == "fetch" else 1.0)
         acc[cls][1] += 1
+        if cls in ("gemm_bf16_kernel", "gemm_h2_kernel"):
+            pk = parts[cls].setdefault(name[:72], {"fetch": [0.0, 0], "write": [0.0, 0]})
+            pk[tag][0] += val * 1024.0 * (2.0 if tag == "fetch" else 1.0)
+            pk[tag][1] += 1
     for k, (b, n) in acc.items():
         out.setdefault(k, {})[tag + "_bytes_per_launch"] = b / max(n, 1)
         out[k]["launches_" + tag] = n
+for cls, pp in parts.items():
+    out[cls]["parts"] = {k: {"launches": v["fetch"][1], "fetch_MB_per_launch": round(v["fetch"][0] / max(v["fetch"][1], 1) / 1e6, 1),
+                             "write_MB_per_launch": round(v["write"][0] / max(v["write"][1], 1) / 1e6, 1)}
+                         for k, v in sorted(pp.items(), key=lambda kv: -kv[1]["fetch"][0])}
 print(json.dumps(out, indent=1))
