@@ -128,6 +128,48 @@ def run_sot(exp_name, H, W):
     print(exp_name, {k: v.shape for k, v in out.items() if not k.endswith("__shape") and not k.endswith("__stats")})
 
 
+def run_vos(exp_name, H, W):
+    """get_det_results of the VOS driver (external/lib/test/tracker/unicorn_vos.py:157-200) with the REAL reference model's modes and the
+    reference's own postprocess_inst: one interaction / upsample / correlation for the frame pair, then PER OBJECT label-map
+    propagation, head(mode="sot"), CondInst masks; the best instance per object (:131-152) is stored.  Only `.cuda()` / fp16 casts are
+    dropped (CPU, fp32 correlation = the parity definition)."""
+    cfg = uo.CONFIGS[exp_name]
+    model, exp = rb.build_reference_model(exp_name)
+    load_synth(model, cfg)
+    from unicorn.utils.boxes import postprocess_inst
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    boxes = {"1": box, "2": torch.tensor([W * 0.55, H * 0.1, W * 0.9, H * 0.45]), "3": torch.tensor([W * 0.1, H * 0.55, W * 0.4, H * 0.95])}
+    out = {}
+    with torch.no_grad():
+        _, d_pre = model(imgs=frames[0], mode="backbone")
+        lbs = {}
+        for k, b in boxes.items():                                  # unicorn_vos.py:52-56 (get_label_map + 1/8 bilinear)
+            lab = torch.zeros((1, 1, H, W))
+            x1, y1, x2, y2 = torch.round(b).int().tolist()
+            lab[0, 0, max(0, min(y1, H)):max(0, min(y2, H)), max(0, min(x1, W)):max(0, min(x2, W))] = 1.0
+            lbs[k] = F.interpolate(lab, scale_factor=1 / 8, mode="bilinear", align_corners=False)[0].flatten(-2)
+        fpn, d_cur = model(imgs=frames[1], mode="backbone")
+        f_pre, f_cur = model(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")          # :162
+        e_pre = model(feat=f_pre, mode="upsample").flatten(-2).squeeze()                        # :164-167
+        e_cur = model(feat=f_cur, mode="upsample").flatten(-2).squeeze()
+        trans = torch.softmax(torch.mm(e_pre.transpose(1, 0), e_cur), dim=0)                    # :173-174
+        dh, dw = d_cur["h"] * 2, d_cur["w"] * 2
+        for k in boxes:                                                                         # :178-200
+            coarse = (lbs[k] @ trans).view(1, -1, dh, dw).float()
+            pri = (coarse, F.interpolate(coarse, scale_factor=1 / 2, mode="bilinear", align_corners=False),
+                   F.interpolate(coarse, scale_factor=1 / 4, mode="bilinear", align_corners=False))
+            o, loc, dyn, lev, mf, um = model.head(fpn, pri, mode="sot")
+            dets, masks = postprocess_inst(o, loc, dyn, lev, mf, model.head.mask_head, 1, 0.001, 0.65, class_agnostic=False,
+                                           d_rate=cfg.d_rate, up_masks=um[0:1])
+            out["n_det_%s" % k] = np.array([0 if dets[0] is None else dets[0].shape[0]])
+            if dets[0] is not None:
+                pack(out, "det_%s" % k, dets[0][0])
+                out["mask_bits_%s" % k] = np.packbits((masks[0][0, 0] > 0.5).numpy().astype(np.uint8).reshape(-1))
+                pack(out, "mask_%s" % k, masks[0][0, 0][::4, ::4])
+    np.savez_compressed(os.path.join(HERE, "%s_vos_%dx%d.npz" % (exp_name, H, W)), **out)
+    print(exp_name, "vos", {k: v.shape for k, v in out.items() if not k.endswith("__shape") and not k.endswith("__stats")})
+
+
 def run_msda_known_answer():
     """unicorn/models/ops/test.py:24-50 shapes & seed; answer = the reference's own pure-PyTorch core."""
     rb.boot()
@@ -174,3 +216,5 @@ if __name__ == "__main__":
     run_sot("unicorn_track_large", 320, 320)
     run_sot("unicorn_track_large_mask", 320, 320)
     run_sot("unicorn_track_large_mot_challenge", 320, 320)
+    run_vos("unicorn_track_tiny_mask", 320, 320)
+    run_vos("unicorn_track_large_mask", 320, 320)

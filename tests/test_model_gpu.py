@@ -372,6 +372,35 @@ def test_large_mask_vos_k3_tracker_step_vs_oracle():
     assert met["box_iou_min"] > 0.999 and met["mask_iou_min"] > 0.999, met
 
 
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny_mask", "unicorn_track_large_mask"])
+def test_vos_tracker_step_vs_reference_golden(exp, golden_dir):
+    """UnicornVOSTrack.step (K = 3 objects, one correlation pass + one object-batched head call) against vectors of the REAL reference
+    (tests/golden/make_golden.py:run_vos = unicorn_vos.py:157-200 on the reference model): best box per object, mask bits, f16x2."""
+    from unicorn_amd.tracker import UnicornVOSTrack
+    H = W = 320
+    g = np.load(os.path.join(golden_dir, "%s_vos_%dx%d.npz" % (exp, H, W)))
+    m, cfg, P = build(exp, "f16x2")
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    boxes = {"1": box, "2": torch.tensor([W * 0.55, H * 0.1, W * 0.9, H * 0.45]), "3": torch.tensor([W * 0.1, H * 0.55, W * 0.4, H * 0.95])}
+    trk = UnicornVOSTrack(m, input_size=(H, W), d_rate=cfg.d_rate)
+    trk.initialize(frames[0].cuda(), {"init_object_ids": list(boxes), "init_bbox": {k: [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])]
+                                                                                    for k, b in boxes.items()}})
+    res, _ = trk.step(frames[1].cuda())
+    cx = lambda t: torch.stack([(t[0] + t[2]) / 2, (t[1] + t[3]) / 2, t[2] - t[0], t[3] - t[1]])[None]
+    for k in boxes:
+        d_h, m_h = res[k]
+        assert (d_h is None) == (int(g["n_det_%s" % k][0]) == 0), k
+        if d_h is None:
+            continue
+        ref = torch.from_numpy(g["det_%s" % k])
+        ref[0:4:2] = ref[0:4:2].clamp(0, W)                          # the driver clamps to the input size (unicorn_vos.py:133-134)
+        ref[1:4:2] = ref[1:4:2].clamp(0, H)
+        assert float(box_iou_pairs(cx(d_h.cpu()), cx(ref))[0]) > 0.999, (k, d_h, ref)
+        bits = np.packbits((m_h.cpu() > 0.5).numpy().astype(np.uint8).reshape(-1))
+        diff = np.unpackbits(bits ^ g["mask_bits_%s" % k]).sum()
+        assert diff <= 1e-3 * m_h.numel(), (k, int(diff))
+
+
 def test_vos_tracker_reference_groups_raw_images_vs_oracle():
     """Row N3a + N1: the full driver on RAW uint8 frames (letterbox r != 1, so the resize of the aggregation is exercised),
     with an object that APPEARS AT FRAME 2 (info["init_object_ids"] / init_bbox / init_mask, unicorn_vos.py:87-98): from frame 3

@@ -106,6 +106,33 @@ def test_sot_step_matches_reference(exp, golden_dir):
             check(g, "inst_embed", emb)
 
 
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny_mask", "unicorn_track_large_mask"])
+def test_vos_step_matches_reference(exp, golden_dir):
+    """BASELINE.json configs[3] in small: the VOS driver's get_det_results (unicorn_vos.py:157-200) for K = 3 objects, produced with the REAL
+    reference model + its postprocess_inst (tests/golden/make_golden.py:run_vos): best instance and its CondInst mask per object."""
+    torch.set_num_threads(8)
+    H = W = 320
+    g = np.load(os.path.join(golden_dir, "%s_vos_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = synth.synth_state_dict(cfg)
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    boxes = {"1": box, "2": torch.tensor([W * 0.55, H * 0.1, W * 0.9, H * 0.45]), "3": torch.tensor([W * 0.1, H * 0.55, W * 0.4, H * 0.95])}
+    with torch.no_grad():
+        st = uo.vos_init(P, cfg, frames[0], boxes)
+        res = uo.vos_step(P, cfg, st, frames[1])
+    for k in boxes:
+        det, mask = res[k]
+        assert (det is None) == (int(g["n_det_%s" % k][0]) == 0), k
+        if det is None:
+            continue
+        ref = torch.from_numpy(g["det_%s" % k])
+        assert (det[:4] - ref[:4]).abs().max() < 2e-2 and (det[4:6] - ref[4:6]).abs().max() < 1e-5 * max(1.0, float(ref[4:6].abs().max())) + 1e-6, (k, det, ref)
+        bits = np.packbits((mask > 0.5).numpy().astype(np.uint8).reshape(-1))
+        diff = np.unpackbits(bits ^ g["mask_bits_%s" % k]).sum()
+        assert diff <= 1e-4 * mask.numel(), (k, diff)
+        check(g, "mask_%s" % k, mask[::4, ::4])
+
+
 def test_letterbox_oracle_known_answers():
     """oracle/letterbox_oracle.py restates cv2.resize(INTER_LINEAR, uint8) (third-party, absent offline): properties every
     correct implementation has -- identity, constants, the 3:1 / 1:3 pattern of an exact 2x upsample, the rounded 2x2 mean of
