@@ -475,7 +475,9 @@ __global__ __launch_bounds__(384) void dwconv7_ln2_kernel(DwLnArgs p, int S, int
 //   * LayerNorm sums reduced inside the waves (reduce-scatter butterfly: 17 shuffles for the 16 pixels), 64 B of scratch per wave.
 // ROWS = 4 output rows per thread: the measured bound of these kernels is the L2 -> CU load path (~22-25 B/clk/CU, the same figure
 // the GEMM's LDS-DMA sees), and 10 input rows for 4 output rows is 4.4 input float4s per output float4 instead of 7.
-template <int C, int ROWS>                                     // C compile-time: the tap offsets become instruction immediates
+// DBG (tools/dwln_bench.py with UNI_DW_DBG, C = 768 / ROWS = 2 only): ablation builds -- 1 no input loads, 2 no LayerNorm reductions
+// (local statistics), 4 no output stores, 8 no FMAs.  DBG = 0 is the kernel the engine runs.
+template <int C, int ROWS, int DBG = 0>                        // C compile-time: the tap offsets become instruction immediates
 __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int spr, int nstrips) {
     constexpr int PX = 8, IN = PX + 6, CG = C / 4;
     extern __shared__ float lds[];
@@ -594,18 +596,22 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
             };
             f32x4 ra[IN], wa[7], wb[7];
             ld_w(wa, 0);                                         // pair (r = 0, q = 0): tap row 0
+            if (DBG & 1) {
+#pragma unroll
+                for (int j = 0; j < IN; ++j) ra[j] = f32x4{1.f, 2.f, 3.f, 4.f};
+            }
 #pragma unroll 1
             for (int r = 0; r < 6 + ROWS; ++r) {                 // input row y-3+r feeds output row y+q with tap row ky = r - q
-                load_row(ra, y - 3 + r);
+                if (!(DBG & 1)) load_row(ra, y - 3 + r);
 #pragma unroll
                 for (int q = 0; q < ROWS; q += 2) {
                     ld_w(wb, r - (q + 1));                       // next pair: (r, q + 1)
                     __builtin_amdgcn_sched_barrier(0);
-                    if (r - q >= 0 && r - q < 7) mac(acc[q], wa, ra);
+                    if (!(DBG & 8) && r - q >= 0 && r - q < 7) mac(acc[q], wa, ra);
                     __builtin_amdgcn_sched_barrier(0);
                     ld_w(wa, q + 2 < ROWS ? r - (q + 2) : r + 1); // (r, q + 2), or (r + 1, 0)
                     __builtin_amdgcn_sched_barrier(0);
-                    if (r - q - 1 >= 0 && r - q - 1 < 7) mac(acc[q + 1], wb, ra);
+                    if (!(DBG & 8) && r - q - 1 >= 0 && r - q - 1 < 7) mac(acc[q + 1], wb, ra);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                 const f32x4 v = acc[2 * h + (u >> 3)][u & 7];
                 part[u] = lane_ok ? v[0] + v[1] + v[2] + v[3] : 0.f;
             }
-            reduce16(part, tot);
+            if (DBG & 2) { for (int u = 0; u < 16; ++u) tot[u] = part[u] * (float)CG; } else reduce16(part, tot);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const float m = tot[u] * invC;
@@ -629,11 +635,11 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                 const float a = v[0] - m, b = v[1] - m, c = v[2] - m, d = v[3] - m;
                 part[u] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
             }
-            reduce16(part, tot);
+            if (DBG & 2) { for (int u = 0; u < 16; ++u) tot[u] = part[u] * (float)CG; } else reduce16(part, tot);
 #pragma unroll
             for (int u = 0; u < 16; ++u) rstd[2 * h + (u >> 3)][u & 7] = rsqrtf(tot[u] * invC + p.eps);
         }
-        if (active && lane_ok) {
+        if (active && lane_ok && !((DBG & 4) && p.eps > 0.f)) {       // (DBG 4: the results stay live through the runtime eps test, nothing is stored)
             // 16-byte stores: a lane owns 4 channels = 8 bytes of hi + 8 of lo (f16x2) or 8 bytes of bf16, and 8-byte stores are
             // store-issue bound (32 per thread and tile).  Lane pairs (cg, cg ^ 1; CG is even) swap halves through DPP: f16x2 --
             // the even lane writes the 16 hi bytes of the 8-channel group, the odd lane the 16 lo bytes; bf16 -- the even lane writes
@@ -729,6 +735,13 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                     attr_done = true;
                 }
                 const dim3 grid(256), block(Sw * wps * 64);
+                static const int dbg = getenv("UNI_DW_DBG") ? atoi(getenv("UNI_DW_DBG")) : 0;      // ablation builds of the stage-2 kernel (tools/dwln_bench.py)
+                if (dbg && a.C == 768 && rows == 2) {
+#define DWB_DBG(D) if (dbg == D) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<768, 2, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                                   hipLaunchKernelGGL((dwconv7_lnb_kernel<768, 2, D>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
+                    DWB_DBG(1) DWB_DBG(2) DWB_DBG(4) DWB_DBG(8) DWB_DBG(3) DWB_DBG(9) DWB_DBG(15)
+#undef DWB_DBG
+                }
 #define DWB_GO(CC, RR) if (a.C == CC && rows == RR) { hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, RR>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
                 DWB_ALL(DWB_GO)
 #undef DWB_GO
