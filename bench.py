@@ -418,6 +418,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     dist, dgroup, dinfo = None, None, None
+    if torch.cuda.is_available():
+        # the rank's GPU must be current BEFORE any RCCL communicator is created (a communicator binds to the current device: with the
+        # default device every rank would sit on GPU 0 and RCCL reports "Duplicate GPU detected")
+        if os.environ.get("UNI_BENCH_SHARE_GPU"):      # plumbing test of the N > 1 path on a one-GPU box: all ranks on GPU 0
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
     if world > 1:          # N = 1 (also under torchrun) never touches torch.distributed: same code path as the plain run
         dist, dgroup, dinfo = init_dist(rank, local_rank, world, torch.cuda.is_available())
         assert dist.get_world_size() == args.gpus
@@ -450,9 +456,6 @@ def main():
             dist.destroy_process_group()
         return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the measured path)"
-    if os.environ.get("UNI_BENCH_SHARE_GPU"):      # plumbing test of the N > 1 path on a one-GPU box (with UNI_BENCH_BACKEND=gloo): all ranks on GPU 0
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import synth
