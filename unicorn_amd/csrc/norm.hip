@@ -477,8 +477,10 @@ __global__ __launch_bounds__(384) void dwconv7_ln2_kernel(DwLnArgs p, int S, int
 // the GEMM's LDS-DMA sees), and 10 input rows for 4 output rows is 4.4 input float4s per output float4 instead of 7.
 // DBG (tools/dwln_bench.py with UNI_DW_DBG, C = 768 / ROWS = 2 only): ablation builds -- 1 no input loads, 2 no LayerNorm reductions
 // (local statistics), 4 no output stores, 8 no FMAs.  DBG = 0 is the kernel the engine runs.
-template <int C, int ROWS, int DBG = 0>                        // C compile-time: the tap offsets become instruction immediates
-__global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int spr, int nstrips) {
+// NW = 12 (ROWS = 2, round 4): twelve waves per block = THREE per SIMD (<= 168 registers: one 7-tap buffer re-read in place instead of the tap double
+// buffer).  A PMC pass showed the 8-wave kernel at C = 768 as 6 waves on 4 SIMDs (two SIMDs 52 % VALU-busy, two 26 %) with 43 % of the wave cycles waiting.
+template <int C, int ROWS, int DBG = 0, int NW = 8>            // C compile-time: the tap offsets become instruction immediates
+__global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S, int spr, int nstrips) {
     constexpr int PX = 8, IN = PX + 6, CG = C / 4;
     extern __shared__ float lds[];
     float* wl = lds;                                             // [49][C]
@@ -594,6 +596,40 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[o][e] = fmaf(w[kx][e], src[o + kx][e], a[o][e]);
             };
+            if constexpr (NW == 12) {
+                // one 7-tap buffer: each tap is re-read IN PLACE for the next (input row, output row) pair right after its last use (one tap = 16
+                // packed FMAs = 64 cycles, the read has six taps of slack).  Pair sequence (r, q) = (0,0) (0,1) (1,0) (1,1) ...: tap row ky = r - q;
+                // the pair after (r, 0) is (r, 1) with tap row r - 1, the pair after (r, 1) is (r + 1, 0) with tap row r + 1 (clamped: out-of-range
+                // pairs multiply nothing and only pass the taps on)
+                f32x4 ra[IN], w[7];
+                {
+                    const float* wrow = wl + cg * 4;
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(wrow + kx * C);
+                }
+                auto pair = [&](f32x4 (&a)[PX], int ky, int nk) __attribute__((always_inline)) {
+                    const float* wn = wl + (min(max(nk, 0), 6) * 7) * C + cg * 4;
+                    if (!(DBG & 8) && ky >= 0 && ky < 7) {           // wave-uniform
+#pragma unroll
+                        for (int kx = 0; kx < 7; ++kx) {
+#pragma unroll
+                            for (int o = 0; o < PX; ++o)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a[o][e] = fmaf(w[kx][e], ra[o + kx][e], a[o][e]);
+                            w[kx] = *reinterpret_cast<const f32x4*>(wn + kx * C);
+                        }
+                    } else {
+#pragma unroll
+                        for (int kx = 0; kx < 7; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(wn + kx * C);
+                    }
+                };
+#pragma unroll 1
+                for (int r = 0; r < 8; ++r) {
+                    load_row(ra, y - 3 + r);
+                    pair(acc[0], r, r - 1);
+                    pair(acc[1], r - 1, r + 1);
+                }
+            } else {
             f32x4 ra[IN], wa[7], wb[7];
             ld_w(wa, 0);                                         // pair (r = 0, q = 0): tap row 0
             if (DBG & 1) {
@@ -614,6 +650,7 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                     if (!(DBG & 8) && r - q - 1 >= 0 && r - q - 1 < 7) mac(acc[q + 1], wb, ra);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             }
         }
         // LayerNorm per pixel: two-pass (mean, then centred variance), 16 pixels per reduction
@@ -656,7 +693,15 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
 #pragma unroll
             for (int q = 0; q < ROWS; ++q) {
                 if (y + q >= p.H) continue;
-                const size_t prow = (img0 + (size_t)(y + q) * p.W + x0) * C + (cg & ~1) * 4;    // element index of the lane pair's 8-channel group, pixel x0
+                // one buffer descriptor per output PIXEL (scalar base + ONE per-lane offset: no 64-bit vector addresses -- the 12-wave build spilled
+                // and re-loaded them in front of every store): num_records = the bytes from this pixel to the end of the row, so a pixel past the
+                // row end (and the odd lane's pixel o + 1 of the bf16 pairing) is dropped by the range check.  (The check covers the per-lane
+                // offset only, NOT a scalar offset: the pixel must sit in the base.)
+                const int eb = p.b32 == FMT_BF16 ? 2 : 4;
+                char* orow = reinterpret_cast<char*>(p.out) + (img0 + (size_t)(y + q) * p.W + x0) * C * eb;
+                auto odesc = [&](int o) __attribute__((always_inline)) {
+                    return __builtin_amdgcn_make_buffer_rsrc(orow + (size_t)o * C * eb, 0, max(p.W - x0 - o, 0) * C * eb, 0x00020000);
+                };
                 if (p.b32 == FMT_H2) {
 #pragma unroll
                     for (int o = 0; o < PX; ++o) {
@@ -669,8 +714,7 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                         const unsigned s0 = odd ? hu[0] : lu[0], s1 = odd ? hu[1] : lu[1];
                         const unsigned r0 = xor1(s0), r1 = xor1(s1);
                         const u32x4 ov = odd ? u32x4{r0, r1, lu[0], lu[1]} : u32x4{hu[0], hu[1], r0, r1};
-                        if (x0 + o < p.W)
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + (prow + (size_t)o * C) * 4 + (odd ? 16 : 0)) = ov;
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, odesc(o), (cg & ~1) * 16 + (odd ? 16 : 0), 0, 0);
                     }
                 } else if (p.b32 == FMT_BF16) {
 #pragma unroll
@@ -683,15 +727,15 @@ __global__ __launch_bounds__(512) void dwconv7_lnb_kernel(DwLnArgs p, int S, int
                         const unsigned s0 = odd ? u0[0] : u1[0], s1 = odd ? u0[1] : u1[1];
                         const unsigned r0 = xor1(s0), r1 = xor1(s1);
                         const u32x4 ov = odd ? u32x4{r0, r1, u1[0], u1[1]} : u32x4{u0[0], u0[1], r0, r1};
-                        const int oo = o + (odd ? 1 : 0);
-                        if (x0 + oo < p.W) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.out) + prow + (size_t)oo * C) = ov;
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, odesc(o), (cg & ~1) * 8 + (odd ? C * 2 : 0), 0, 0);      // the odd lane's pixel o + 1 sits in its lane offset
                     }
                 } else {
 #pragma unroll
                     for (int o = 0; o < PX; ++o) {
                         float yv[4];
                         norm4(q, o, yv);
-                        if (x0 + o < p.W) act_store4(p.out, (img0 + (size_t)(y + q) * p.W + x0 + o) * C + cg * 4, yv[0], yv[1], yv[2], yv[3], p.b32);
+                        const f32x4 yo = {yv[0], yv[1], yv[2], yv[3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yo), odesc(o), cg * 16, 0, 0);
                     }
                 }
             }
@@ -741,6 +785,17 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                                    hipLaunchKernelGGL((dwconv7_lnb_kernel<768, 2, D>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
                     DWB_DBG(1) DWB_DBG(2) DWB_DBG(4) DWB_DBG(8) DWB_DBG(3) DWB_DBG(9) DWB_DBG(15)
 #undef DWB_DBG
+                }
+                // 12 waves per block (three per SIMD) for C = 768 / 384: 177 -> 147 us and 313 -> 298 us on the stage-2 / stage-1 maps at 16 frames
+                // (C = 192: 598 -> 676 us, stays on 8 waves).  UNI_DW_W12 = 0 / 1 / 2: off / default / also C = 192 (A/B switch).
+                static const int w12 = getenv("UNI_DW_W12") ? atoi(getenv("UNI_DW_W12")) : 1;
+                if (w12 && rows == 2 && (a.C == 384 || a.C == 768 || (w12 == 2 && a.C == 192))) {
+                    const int Sw12 = 12 / wps;
+                    const size_t lds12 = (size_t)49 * a.C * 4 + (size_t)12 * 16 * 4;
+#define DWB_W12(CC) if (a.C == CC) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                                     hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, 2, 0, 12>), grid, dim3(Sw12 * wps * 64), lds12, s, a, Sw12, spr, nst); return 0; }
+                    DWB_W12(192) DWB_W12(384) DWB_W12(768)
+#undef DWB_W12
                 }
 #define DWB_GO(CC, RR) if (a.C == CC && rows == RR) { hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, RR>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
                 DWB_ALL(DWB_GO)
