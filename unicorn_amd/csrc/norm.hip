@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
     constexpr int PX = 8, IN = PX + 6, CG = C / 4;
     extern __shared__ float lds[];
     float* wl = lds;                                             // [49][C]
-    float* red = lds + 49 * C;                                   // [waves][16]
+    float* red = lds + 49 * C;                                   // [2][waves][16]
     const int tid = threadIdx.x;
     for (int u = tid; u < 49 * C / 4; u += blockDim.x) reinterpret_cast<f32x4*>(wl)[u] = reinterpret_cast<const f32x4*>(p.w)[u];
     __syncthreads();
@@ -533,20 +533,26 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
         a1 += __shfl_xor(a1, 2, 64);
         return a1 + __shfl_xor(a1, 1, 64);
     };
-    auto reduce16 = [&](const float (&part)[16], float (&tot)[16]) __attribute__((always_inline)) {
+    // `buf` alternates between the two scratch buffers from one reduction to the next: ONE barrier per reduction is enough (a wave that writes
+    // buffer b again has passed the barrier of the reduction in between, which every wave reaches only after its reads of b)
+    auto reduce16 = [&](const float (&part)[16], float (&tot)[16], int buf) __attribute__((always_inline)) {
         const float t = wave_scatter_sum(part);
-        if ((lane & 3) == 0) red[wv * 16 + (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1))] = t;
+        float* rb = red + buf * (NW * 16);
+        if ((lane & 3) == 0) rb[wv * 16 + (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1))] = t;
         // a strip that is ONE wave (C <= 256) needs no block barrier: the strips of a block are independent
         if (wps == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
         else __syncthreads();
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            float t2 = 0.f;
-            for (int w_ = 0; w_ < wps; ++w_) t2 += red[(sl * wps + w_) * 16 + o];     // fixed order: deterministic
-            tot[o] = t2;
+        for (int o = 0; o < 16; ++o) tot[o] = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < wps; ++w_) {                       // fixed order: deterministic; four 16-byte broadcast reads per wave of the strip
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(rb + (sl * wps + w_) * 16 + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[4 * g4 + e] += v4[e];
+            }
         }
-        if (wps == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-        else __syncthreads();
     };
 #pragma unroll 1
     for (int it = 0; it < count; ++it) {
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
                 const f32x4 v = acc[2 * h + (u >> 3)][u & 7];
                 part[u] = lane_ok ? v[0] + v[1] + v[2] + v[3] : 0.f;
             }
-            if (DBG & 2) { for (int u = 0; u < 16; ++u) tot[u] = part[u] * (float)CG; } else reduce16(part, tot);
+            if (DBG & 2) { for (int u = 0; u < 16; ++u) tot[u] = part[u] * (float)CG; } else reduce16(part, tot, 0);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const float m = tot[u] * invC;
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
                 const float a = v[0] - m, b = v[1] - m, c = v[2] - m, d = v[3] - m;
                 part[u] = lane_ok ? a * a + b * b + c * c + d * d : 0.f;
             }
-            if (DBG & 2) { for (int u = 0; u < 16; ++u) tot[u] = part[u] * (float)CG; } else reduce16(part, tot);
+            if (DBG & 2) { for (int u = 0; u < 16; ++u) tot[u] = part[u] * (float)CG; } else reduce16(part, tot, 1);
 #pragma unroll
             for (int u = 0; u < 16; ++u) rstd[2 * h + (u >> 3)][u & 7] = rsqrtf(tot[u] * invC + p.eps);
         }
@@ -767,7 +773,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
             static const int rows_env = getenv("UNI_DW_ROWS") ? atoi(getenv("UNI_DW_ROWS")) : 0;
             const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (a.C == 256 || a.C == 512 ? 4 : 2);
             const int wps = cdiv(CG, 64), Sw = 8 / wps;          // 512 threads: 8 waves
-            const size_t ldsw = (size_t)49 * a.C * 4 + (size_t)8 * 16 * 4;
+            const size_t ldsw = (size_t)49 * a.C * 4 + (size_t)2 * 8 * 16 * 4;
             const int nst = spr * cdiv(a.H, rows) * nb;
             if (cdiv(nst, Sw) >= 384) {
                 static bool attr_done = false;
@@ -791,7 +797,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                 static const int w12 = getenv("UNI_DW_W12") ? atoi(getenv("UNI_DW_W12")) : 1;
                 if (w12 && rows == 2 && (a.C == 384 || a.C == 768 || (w12 == 2 && a.C == 192))) {
                     const int Sw12 = 12 / wps;
-                    const size_t lds12 = (size_t)49 * a.C * 4 + (size_t)12 * 16 * 4;
+                    const size_t lds12 = (size_t)49 * a.C * 4 + (size_t)2 * 12 * 16 * 4;
 #define DWB_W12(CC) if (a.C == CC) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                                      hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, 2, 0, 12>), grid, dim3(Sw12 * wps * 64), lds12, s, a, Sw12, spr, nst); return 0; }
                     DWB_W12(192) DWB_W12(384) DWB_W12(768)
