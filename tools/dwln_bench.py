@@ -7,7 +7,10 @@ from unicorn_amd import _lib as L
 lib = L.lib()
 B = int(os.environ.get("B", "16"))
 FMT = int(os.environ.get("FMT", "2"))
-for (C, H, W) in [(768, 50, 80), (192, 200, 320), (384, 100, 160), (256, 100, 160), (256, 50, 80)]:
+SHAPES = [(768, 50, 80), (192, 200, 320), (384, 100, 160), (256, 100, 160), (256, 50, 80), (1536, 25, 40), (256, 25, 40)]
+if os.environ.get("SHAPES"):      # e.g. SHAPES=1536x25x40,256x25x40
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
+for (C, H, W) in SHAPES:
     x = torch.randn(B, H, W, C, device="cuda")
     w = torch.randn(49, C, device="cuda") * 0.1
     b, g, be = torch.randn(C, device="cuda"), torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
