@@ -479,20 +479,34 @@ __global__ __launch_bounds__(384) void dwconv7_ln2_kernel(DwLnArgs p, int S, int
 // (local statistics), 4 no output stores, 8 no FMAs.  DBG = 0 is the kernel the engine runs.
 // NW = 12 (ROWS = 2, round 4): twelve waves per block = THREE per SIMD (<= 168 registers: one 7-tap buffer re-read in place instead of the tap double
 // buffer).  A PMC pass showed the 8-wave kernel at C = 768 as 6 waves on 4 SIMDs (two SIMDs 52 % VALU-busy, two 26 %) with 43 % of the wave cycles waiting.
-template <int C, int ROWS, int DBG = 0, int NW = 8>            // C compile-time: the tap offsets become instruction immediates
+// PACK (C = 384 / 192, round 4): CG = 96 / 48 channel groups leave a quarter of the lanes of a strip's waves idle.  Packed, TWO (C = 384) or FOUR
+// (C = 192) strips side by side in x -- a "strip group" of 16 / 32 px -- fill exactly three waves: flat lane f of the group is channel group f % CG of
+// strip f / CG.  Everything about the ROW stays wave-uniform; the strip of a lane is 8 px * (f / CG) further right, which travels in the per-lane
+// buffer offset (descriptor base AT the first pixel, so the range check drops whatever lies past the row end; at the left image edge the base sits
+// on the second strip's pixel and the first strip's lanes carry a negative = out-of-range offset).  The LayerNorm sums are reduce-scattered inside
+// 32- / 16-lane granules (three granules per strip, like the three waves of a C = 768 strip).  S / spr / nstrips then count strip GROUPS.
+template <int C, int ROWS, int DBG = 0, int NW = 8, bool PACK = false>            // C compile-time: the tap offsets become instruction immediates
 __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S, int spr, int nstrips) {
     constexpr int PX = 8, IN = PX + 6, CG = C / 4;
+    static_assert(!PACK || CG == 96 || CG == 48, "packed lanes: C = 384 / 192");
+    constexpr int G = !PACK ? 64 : (CG % 32 == 0 ? 32 : 16);    // lanes of a reduction granule
+    constexpr int LG = G == 64 ? 2 : G == 32 ? 1 : 0;            // lane bits below the four reduce-scatter bits
+    constexpr int NSLOT = NW * 64 / G;                           // granules of a block
     extern __shared__ float lds[];
     float* wl = lds;                                             // [49][C]
     float* red = lds + 49 * C;                                   // [2][waves][16]
     const int tid = threadIdx.x;
     for (int u = tid; u < 49 * C / 4; u += blockDim.x) reinterpret_cast<f32x4*>(wl)[u] = reinterpret_cast<const f32x4*>(p.w)[u];
     __syncthreads();
-    constexpr int wps = (CG + 63) >> 6;                          // waves per strip; C = 192 / 384 leave the lanes past CG idle
+    constexpr int wps = PACK ? 3 : (CG + 63) >> 6;               // waves per strip (group); unpacked, C = 192 / 384 leave the lanes past CG idle
+    constexpr int NGS = PACK ? CG / G : wps;                     // granules per strip
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sl = wv / wps, cg0 = (wv - sl * wps) * 64 + lane;
-    const bool lane_ok = cg0 < CG;
+    const int sl = wv / wps, fl = (wv - sl * wps) * 64 + lane;
+    const int ks = PACK ? fl / CG : 0;                           // strip of the group (per lane)
+    const int cg0 = fl - ks * CG;
+    const bool lane_ok = PACK || cg0 < CG;
     const int cg = lane_ok ? cg0 : 0;                            // idle lanes shadow channel group 0 and store nothing
+    const int kso = ks * PX * C;                                 // the lane's strip in elements from the group's first pixel
     int first, step, count;
     {
         const int nblk = (nstrips + S - 1) / S;
@@ -507,48 +521,50 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
     const int HP = (p.H + ROWS - 1) / ROWS;                      // row groups per image
     constexpr float invC = 1.f / (float)C;
     const int rowbytes = p.W * C * 4;
-    // sum over the lanes of a wave of 16 values at once: afterwards every lane holds the total of value
-    // ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
+    // sum over the lanes of a G-lane granule (G = 64: the wave) of 16 values at once: afterwards every lane holds the granule total of value
+    // (lane >> LG) & 15
     auto wave_scatter_sum = [&](const float (&v)[16]) __attribute__((always_inline)) {
         float a8[8], a4[4], a2[2], a1;
         {
-            const bool up = (lane >> 5) & 1;
+            const bool up = (lane >> (LG + 3)) & 1;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a8[r] = (up ? v[r + 8] : v[r]) + __shfl_xor(up ? v[r] : v[r + 8], 32, 64);
+            for (int r = 0; r < 8; ++r) a8[r] = (up ? v[r + 8] : v[r]) + __shfl_xor(up ? v[r] : v[r + 8], 8 << LG, 64);
         }
         {
-            const bool up = (lane >> 4) & 1;
+            const bool up = (lane >> (LG + 2)) & 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a4[r] = (up ? a8[r + 4] : a8[r]) + __shfl_xor(up ? a8[r] : a8[r + 4], 16, 64);
+            for (int r = 0; r < 4; ++r) a4[r] = (up ? a8[r + 4] : a8[r]) + __shfl_xor(up ? a8[r] : a8[r + 4], 4 << LG, 64);
         }
         {
-            const bool up = (lane >> 3) & 1;
+            const bool up = (lane >> (LG + 1)) & 1;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) a2[r] = (up ? a4[r + 2] : a4[r]) + __shfl_xor(up ? a4[r] : a4[r + 2], 8, 64);
+            for (int r = 0; r < 2; ++r) a2[r] = (up ? a4[r + 2] : a4[r]) + __shfl_xor(up ? a4[r] : a4[r + 2], 2 << LG, 64);
         }
         {
-            const bool up = (lane >> 2) & 1;
-            a1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 4, 64);
+            const bool up = (lane >> LG) & 1;
+            a1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 1 << LG, 64);
         }
-        a1 += __shfl_xor(a1, 2, 64);
-        return a1 + __shfl_xor(a1, 1, 64);
+        if (LG >= 2) a1 += __shfl_xor(a1, 2, 64);
+        if (LG >= 1) a1 += __shfl_xor(a1, 1, 64);
+        return a1;
     };
     // `buf` alternates between the two scratch buffers from one reduction to the next: ONE barrier per reduction is enough (a wave that writes
     // buffer b again has passed the barrier of the reduction in between, which every wave reaches only after its reads of b)
     auto reduce16 = [&](const float (&part)[16], float (&tot)[16], int buf) __attribute__((always_inline)) {
         const float t = wave_scatter_sum(part);
-        float* rb = red + buf * (NW * 16);
-        if ((lane & 3) == 0) rb[wv * 16 + (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1))] = t;
+        float* rb = red + buf * (NSLOT * 16);
+        if ((lane & ((1 << LG) - 1)) == 0) rb[((wv * 64 + lane) / G) * 16 + ((lane >> LG) & 15)] = t;
         // a strip that is ONE wave (C <= 256) needs no block barrier: the strips of a block are independent
         if (wps == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
         else __syncthreads();
 #pragma unroll
         for (int o = 0; o < 16; ++o) tot[o] = 0.f;
+        const int slot0 = (sl * wps * 64 + ks * CG) / G;           // first granule of the lane's strip
 #pragma unroll
-        for (int w_ = 0; w_ < wps; ++w_) {                       // fixed order: deterministic; four 16-byte broadcast reads per wave of the strip
+        for (int w_ = 0; w_ < NGS; ++w_) {                       // fixed order: deterministic; four 16-byte broadcast reads per granule of the strip
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 v4 = *reinterpret_cast<const f32x4*>(rb + (sl * wps + w_) * 16 + 4 * g4);
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(rb + (slot0 + w_) * 16 + 4 * g4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tot[4 * g4 + e] += v4[e];
             }
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
         const int strip = (first + it * step) * S + sl;          // wave-uniform
         const bool active = sl < S && strip < nstrips;
         const int yg = active ? strip / spr : 0;
-        const int x0 = active ? (strip - yg * spr) * PX : 0;
+        const int x0 = active ? (strip - yg * spr) * PX * (PACK ? 192 / CG : 1) : 0;
         const int sb = yg / HP, y = (yg - sb * HP) * ROWS;       // sample, first of the output rows
         const size_t img0 = (size_t)sb * p.H * p.W;
         f32x4 acc[ROWS][PX];
@@ -580,9 +596,20 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
 #pragma unroll
                 for (int j = 0; j < IN; ++j) {
                     const int ix = x0 + j - 3;
-                    const bool ok = rok && ix >= 0 && ix < p.W;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, ok ? rowbytes : 0, 0x00020000);
-                    dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cg * 16, ok ? ix * C * 4 : 0, 0));
+                    if constexpr (PACK) {
+                        // descriptor base AT the pixel (the range check covers the per-lane offset only); left of the image (j < 3 of the first
+                        // group of a row) the base is the SECOND strip's pixel and the first strip's lanes carry a negative offset: out of range
+                        const bool neg = j < 3 && ix < 0;
+                        const int ixb = neg ? ix + PX : ix;
+                        const int rec = rok ? max(p.W - ixb, 0) * C * 4 : 0;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp + (size_t)max(ixb, 0) * C, 0, rec, 0x00020000);
+                        const int vo = cg * 16 + kso * 4;
+                        dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, neg ? vo - PX * C * 4 : vo, 0, 0));
+                    } else {
+                        const bool ok = rok && ix >= 0 && ix < p.W;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, ok ? rowbytes : 0, 0x00020000);
+                        dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cg * 16, ok ? ix * C * 4 : 0, 0));
+                    }
                 }
             };
             // Weights: the 7 taps of ONE (input row, output row) pair at a time through a register double buffer -- the reads of the
@@ -602,7 +629,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[o][e] = fmaf(w[kx][e], src[o + kx][e], a[o][e]);
             };
-            if constexpr (NW == 12) {
+            if constexpr (NW > 8) {
                 // one 7-tap buffer: each tap is re-read IN PLACE for the next (input row, output row) pair right after its last use (one tap = 16
                 // packed FMAs = 64 cycles, the read has six taps of slack).  Pair sequence (r, q) = (0,0) (0,1) (1,0) (1,1) ...: tap row ky = r - q;
                 // the pair after (r, 0) is (r, 1) with tap row r - 1, the pair after (r, 1) is (r + 1, 0) with tap row r + 1 (clamped: out-of-range
@@ -720,7 +747,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
                         const unsigned s0 = odd ? hu[0] : lu[0], s1 = odd ? hu[1] : lu[1];
                         const unsigned r0 = xor1(s0), r1 = xor1(s1);
                         const u32x4 ov = odd ? u32x4{r0, r1, lu[0], lu[1]} : u32x4{hu[0], hu[1], r0, r1};
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, odesc(o), (cg & ~1) * 16 + (odd ? 16 : 0), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, odesc(o), (cg & ~1) * 16 + (odd ? 16 : 0) + kso * 4, 0, 0);
                     }
                 } else if (p.b32 == FMT_BF16) {
 #pragma unroll
@@ -733,7 +760,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
                         const unsigned s0 = odd ? u0[0] : u1[0], s1 = odd ? u0[1] : u1[1];
                         const unsigned r0 = xor1(s0), r1 = xor1(s1);
                         const u32x4 ov = odd ? u32x4{r0, r1, u1[0], u1[1]} : u32x4{u0[0], u0[1], r0, r1};
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, odesc(o), (cg & ~1) * 8 + (odd ? C * 2 : 0), 0, 0);      // the odd lane's pixel o + 1 sits in its lane offset
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, odesc(o), (cg & ~1) * 8 + (odd ? C * 2 : 0) + kso * 2, 0, 0);      // the odd lane's pixel o + 1 sits in its lane offset
                     }
                 } else {
 #pragma unroll
@@ -741,7 +768,7 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
                         float yv[4];
                         norm4(q, o, yv);
                         const f32x4 yo = {yv[0], yv[1], yv[2], yv[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yo), odesc(o), cg * 16, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yo), odesc(o), cg * 16 + kso * 4, 0, 0);
                     }
                 }
             }
@@ -791,6 +818,25 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                                    hipLaunchKernelGGL((dwconv7_lnb_kernel<768, 2, D>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
                     DWB_DBG(1) DWB_DBG(2) DWB_DBG(4) DWB_DBG(8) DWB_DBG(3) DWB_DBG(9) DWB_DBG(15)
 #undef DWB_DBG
+                }
+                // packed lanes for C = 384 / 192 (two / four strips side by side fill three waves; see the kernel's header).  UNI_DW_PACK = 0 / 1 (A/B
+                // switch), UNI_DW_PACK_NW = 6 / 9 / 12 waves per block (default per C below)
+                static const int pack = getenv("UNI_DW_PACK") ? atoi(getenv("UNI_DW_PACK")) : 1;
+                if (pack && rows == 2 && (a.C == 384 || a.C == 192)) {
+                    static const int nw_env = getenv("UNI_DW_PACK_NW") ? atoi(getenv("UNI_DW_PACK_NW")) : 0;
+                    const int sps = 192 / CG, sprg = cdiv(spr, sps), nstg = sprg * cdiv(a.H, rows) * nb;
+                    // 12 waves (four groups per block: 602 -> 528 us / 298 -> 265 us on the stage-0 / stage-1 maps at 16 frames; 9 waves 559 / 276, 6 waves
+                    // 579 / 292).  One frame of the stage-0 map has too few groups for 12-wave blocks and measured 1 % slower on 6-wave blocks than unpacked.
+                    const int nw = nw_env == 6 || nw_env == 9 || nw_env == 12 ? nw_env : 12;
+                    const int Sg = nw / 3;
+                    const int gran = a.C == 384 ? 32 : 16;
+                    const size_t ldsp = (size_t)49 * a.C * 4 + (size_t)2 * (nw * 64 / gran) * 16 * 4;
+                    if (cdiv(nstg, Sg) >= 384) {
+#define DWB_PACK(CC, NWW) if (a.C == CC && nw == NWW) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, NWW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                                     hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, 2, 0, NWW, true>), grid, dim3(NWW * 64), ldsp, s, a, Sg, sprg, nstg); return 0; }
+                        DWB_PACK(192, 6) DWB_PACK(192, 9) DWB_PACK(192, 12) DWB_PACK(384, 6) DWB_PACK(384, 9) DWB_PACK(384, 12)
+#undef DWB_PACK
+                    }
                 }
                 // 12 waves per block (three per SIMD) for C = 768 / 384: 177 -> 147 us and 313 -> 298 us on the stage-2 / stage-1 maps at 16 frames
                 // (C = 192: 598 -> 676 us, stays on 8 waves).  UNI_DW_W12 = 0 / 1 / 2: off / default / also C = 192 (A/B switch).
