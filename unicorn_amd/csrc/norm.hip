@@ -798,9 +798,11 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
             // output rows per thread: 4 (4.4 input float4s per output float4 instead of 7) where the 128 accumulators leave the
             // other registers unspilled (C = 256 / 512: one wave per strip), else 2 (tools/dwln_bench.py)
             static const int rows_env = getenv("UNI_DW_ROWS") ? atoi(getenv("UNI_DW_ROWS")) : 0;
-            const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (a.C == 256 || a.C == 512 ? 4 : 2);
+            int rows = rows_env == 2 || rows_env == 4 ? rows_env : (a.C == 256 || a.C == 512 ? 4 : 2);
             const int wps = cdiv(CG, 64), Sw = 8 / wps;          // 512 threads: 8 waves
             const size_t ldsw = (size_t)49 * a.C * 4 + (size_t)2 * 8 * 16 * 4;
+            // a map with too few 4-row strips for 1.5 rounds of blocks (the 50 x 80 head level at 16 frames) still fills them with 2-row strips
+            if (!rows_env && rows == 4 && cdiv(spr * cdiv(a.H, 4) * nb, Sw) < 384) rows = 2;
             const int nst = spr * cdiv(a.H, rows) * nb;
             if (cdiv(nst, Sw) >= 384) {
                 static bool attr_done = false;
@@ -841,7 +843,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                 // 12 waves per block (three per SIMD) for C = 768 / 384: 177 -> 147 us and 313 -> 298 us on the stage-2 / stage-1 maps at 16 frames
                 // (C = 192: 598 -> 676 us, stays on 8 waves).  UNI_DW_W12 = 0 / 1 / 2: off / default / also C = 192 (A/B switch).
                 static const int w12 = getenv("UNI_DW_W12") ? atoi(getenv("UNI_DW_W12")) : 1;
-                if (w12 && rows == 2 && (a.C == 384 || a.C == 768 || (w12 == 2 && a.C == 192))) {
+                if (w12 && rows == 2 && (a.C == 384 || a.C == 768 || (w12 == 2 && a.C == 192))) {      // (C = 256 measured slower on 12 waves: 53.5 vs 45.2 us at 50 x 80)
                     const int Sw12 = 12 / wps;
                     const size_t lds12 = (size_t)49 * a.C * 4 + (size_t)2 * 12 * 16 * 4;
 #define DWB_W12(CC) if (a.C == CC) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
