@@ -313,14 +313,17 @@ class Stream:
 
     def sot_batch(self, img):
         """unicorn_sot.py:78-108 for a batch of current frames against the cached reference frame"""
-        from unicorn_amd.ops import corr_softmax_pv, prior_pyramid
+        from unicorn_amd.ops import corr_softmax_pv, corr_softmax_pv_batched, prior_pyramid
         torch, m = self.torch, self.model
         B = img.shape[0]
         fpn, d_cur = m(imgs=img, mode="backbone")
         f_pre, f_cur = m(seq_dict0=self.d_pre, seq_dict1=d_cur, mode="interaction")
         e_pre = m(feat=f_pre, mode="upsample")
         e_cur = m(feat=f_cur, mode="upsample")
-        pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), self.lbs, precision=self.corr_prec) for b in range(B)], 0)
+        if B > 1 and not os.environ.get("UNI_BENCH_CORR_PER_FRAME"):      # one launch for the frames of the step (A/B switch: per-frame launches)
+            pred = corr_softmax_pv_batched(e_pre, e_cur, self.lbs, precision=self.corr_prec)
+        else:
+            pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), self.lbs, precision=self.corr_prec) for b in range(B)], 0)
         coarse = pred.view(1, B, d_cur["h"] * 2, d_cur["w"] * 2)
         pri = tuple(t.transpose(0, 1).contiguous() for t in prior_pyramid(coarse))
         out = m.head(fpn, pri, mode="sot")

@@ -138,6 +138,12 @@ int uni_msda_fwd(const float* value, const int64_t* spatial_shapes, const int64_
 size_t uni_corr_workspace_bytes(int R, int Q, int K);
 int uni_corr_softmax_pv(const float* e_ref, const float* e_cur, const float* values, float* out, int R, int Q, int D,
                         int K, int precision, void* workspace, size_t workspace_bytes, uni_stream_t stream);
+/* The same for B frames in ONE launch (the time-batched SOT step, unicorn_sot.py:88-105 per frame): e_ref [B,R,128], e_cur [B,Q,128],
+ * values [K,R] shared by the frames (values_per_frame = 0) or [B,K,R] -> out [B,K,Q].  workspace >= uni_corr_workspace_bytes_batched. */
+size_t uni_corr_workspace_bytes_batched(int B, int R, int Q, int K);
+int uni_corr_softmax_pv_batched(const float* e_ref, const float* e_cur, const float* values, float* out, int B, int R, int Q, int D,
+                                int K, int values_per_frame, int precision, void* workspace, size_t workspace_bytes,
+                                uni_stream_t stream);
 int uni_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, uni_stream_t stream);
 int uni_label_map_s8(const float* box_xyxy_dev, float* out, int H, int W, uni_stream_t stream);
 int uni_sample_embeddings(const float* embed_nhwc, int H8, int W8, int C, const float* boxes_xyxy, int ld_boxes, int n,

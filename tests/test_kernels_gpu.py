@@ -406,6 +406,36 @@ def test_corr_softmax_pv(L, R, Q, K, prec):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("case", [
+    # (B, R, Q, K, values per frame, precision)
+    (3, 1600, 1600, 1, False, 2),        # the time-batched SOT step: one shared label map
+    (4, 1000, 1300, 3, True, 2),         # value rows per frame, ragged tiles
+    (2, 4000, 16000, 1, False, 2),       # enough blocks per frame that the reference axis is still split (partial results + batched merge)
+    (5, 700, 900, 16, True, 3),          # 16 value rows, the driver's fp16 class
+    (2, 1500, 1100, 21, False, 2),       # more than 16 value rows: frame by frame
+    (3, 333, 257, 2, True, 0),           # exact-fp32 kernel: frame by frame
+])
+def test_corr_softmax_pv_batched(L, case):
+    """uni_corr_softmax_pv_batched (B frames in one launch) against the oracle per frame and against the per-frame entry point"""
+    from unicorn_amd.ops import corr_softmax_pv, corr_softmax_pv_batched
+    B, R, Q, K, vpf, prec = case
+    g = torch.Generator().manual_seed(B + R + Q)
+    er = torch.randn(B, 128, R, generator=g) * 0.6
+    ec = torch.randn(B, 128, Q, generator=g) * 0.6
+    v = torch.rand((B, K, R) if vpf else (K, R), generator=g)
+    out = corr_softmax_pv_batched(er.cuda(), ec.cuda(), v.cuda(), precision=prec, values_per_frame=vpf)
+    assert out.shape == (B, K, Q)
+    for b in range(B):
+        vb = v[b] if vpf else v
+        one = corr_softmax_pv(er[b].cuda(), ec[b].cuda(), vb.cuda(), precision=prec)
+        assert (out[b] - one).abs().max().item() < 5e-6          # same kernel, another split of the reference axis (fp32 merge order)
+        if prec != 3 and Q <= 2000:
+            ref = uo.correlation_propagate(er[b], ec[b], vb)
+            assert (out[b].cpu() - ref).abs().max().item() < 2e-5
+    with pytest.raises(ValueError):
+        corr_softmax_pv_batched(er.cuda(), ec.cuda(), torch.rand(K + 1, 2, R).cuda(), precision=prec, values_per_frame=False)
+
+
 def test_corr_split_matches_fp32_mfma(L):
     """bf16x3 split (precision 1) against the exact fp32 MFMA kernel (precision 0) at 800x1280 scale with large logits
     (|logit| up to ~60, where softmax amplifies any contraction error), and against an fp64 evaluation"""

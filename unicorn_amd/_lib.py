@@ -39,6 +39,8 @@ PROTOS = {
                            C.c_void_p]),
     "uni_corr_workspace_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "uni_corr_softmax_pv": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uni_corr_workspace_bytes_batched": (C.c_size_t, [c_i, c_i, c_i, c_i]),
+    "uni_corr_softmax_pv_batched": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uni_prior_pyramid": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, C.c_void_p]),
     "uni_label_map_s8": (c_i, [c_f, c_f, c_i, c_i, C.c_void_p]),
     "uni_letterbox": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(C.c_double), C.c_void_p]),

@@ -127,6 +127,12 @@ int uni_corr_softmax_pv(const float* e_ref, const float* e_cur, const float* val
     UNI_REQUIRE(e_ref && e_cur && values && out && workspace, "corr: NULL argument");
     API(launch_corr(e_ref, e_cur, values, out, R, Q, D, K, precision, workspace, workspace_bytes, S(stream)));
 }
+size_t uni_corr_workspace_bytes_batched(int B, int R, int Q, int K) { return corr_workspace_bytes_batched(B, R, Q, K); }
+int uni_corr_softmax_pv_batched(const float* e_ref, const float* e_cur, const float* values, float* out, int B, int R, int Q, int D, int K,
+                                int values_per_frame, int precision, void* workspace, size_t workspace_bytes, uni_stream_t stream) {
+    UNI_REQUIRE(e_ref && e_cur && values && out && workspace, "corr: NULL argument");
+    API(launch_corr_batched(e_ref, e_cur, values, out, B, R, Q, D, K, values_per_frame, precision, workspace, workspace_bytes, S(stream)));
+}
 int uni_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, uni_stream_t stream) {
     UNI_REQUIRE(p8 && p16 && p32, "prior_pyramid: NULL argument");
     API(launch_prior_pyramid(p8, p16, p32, K, H8, W8, S(stream)));

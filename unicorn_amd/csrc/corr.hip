@@ -355,8 +355,16 @@ template <int KV, int NWV, bool H1 = false>
 __global__ __launch_bounds__(64 * NWV) void corr_h2_kernel(const float* __restrict__ eref, const float* __restrict__ ecur,
                                                       const float* __restrict__ v, float* __restrict__ out,
                                                       float* __restrict__ ws, int R, int Q, int K, int nsplit,
-                                                      int rows_per_split) {
+                                                      int rows_per_split, long v_frame_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    {   // blockIdx.z = frame of a batch: [B][R][128] / [B][Q][128] embeddings, [B][K][Q] outputs, value rows shared (stride 0) or per frame
+        const size_t z = blockIdx.z;
+        eref += z * (size_t)R * CD;
+        ecur += z * (size_t)Q * CD;
+        out += z * (size_t)K * Q;
+        ws += z * (size_t)nsplit * Q * (2 + KV);
+        v += z * (size_t)v_frame_stride;
+    }
     constexpr int PLANE = TR * CD;                       // f16 elements per piece plane (32 x 128)
     f16* As = reinterpret_cast<f16*>(smem);              // [2 buffers][2 planes][TR][CD]
     float* Vs = smem + (2 * 2 * PLANE) / 2;              // [2][KV*TR]
@@ -505,6 +513,8 @@ template <int KV>
 __global__ void corr_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int Q, int K, int nsplit) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
+    ws += (size_t)blockIdx.y * nsplit * Q * (2 + KV);          // blockIdx.y = frame of a batch
+    out += (size_t)blockIdx.y * K * Q;
     float M = -INFINITY;
     for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws[((size_t)s * Q + q) * (2 + KV)]);
     float L = 0.f, O[KV];
@@ -535,8 +545,8 @@ int corr_slots(int precision) {     // co-resident blocks on the device: 2 x 4-w
 // Split of the reference axis: every block walks rows/ns rows in 32-row tiles; blocks run in rounds of `slots`, so the
 // cost model is rounds x (tiles per split + fixed per-block overhead).  (A fixed ">= 1024 blocks" target gave 4.2 rounds
 // = 5 at 800x1280, 16 % quantisation loss.)
-int pick_nsplit(int R, int Q, int precision = 0) {
-    const int nqb = cdiv(Q, precision ? QB2 : QB);
+int pick_nsplit(int R, int Q, int precision = 0, int B = 1) {
+    const int nqb = cdiv(Q, precision ? QB2 : QB) * B;
     static const char* env = getenv("UNI_CORR_BLOCKS");
     int maxs = R / 256;               // keep >= 8 tiles per split
     if (maxs < 1) maxs = 1;
@@ -557,18 +567,18 @@ int pick_nsplit(int R, int Q, int precision = 0) {
 
 template <int KV>
 int run(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int K, float* ws, int precision,
-        hipStream_t s) {
-    const int ns = pick_nsplit(R, Q, precision);
+        hipStream_t s, int B = 1, long vfs = 0) {
+    const int ns = pick_nsplit(R, Q, precision, B);
     int rps = cdiv(cdiv(R, ns), TR) * TR;
     const int ns_eff = cdiv(R, rps);   // every split non-empty
     if (precision == 3) {
         size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
-        hipLaunchKernelGGL((corr_h2_kernel<KV, 8, true>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
-                           Q, K, ns_eff, rps);
+        hipLaunchKernelGGL((corr_h2_kernel<KV, 8, true>), dim3(cdiv(Q, QB2), ns_eff, B), dim3(512), lds, s, eref, ecur, v, out, ws, R,
+                           Q, K, ns_eff, rps, vfs);
     } else if (precision == 2) {
         size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
-        hipLaunchKernelGGL((corr_h2_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff), dim3(512), lds, s, eref, ecur, v, out, ws, R,
-                           Q, K, ns_eff, rps);
+        hipLaunchKernelGGL((corr_h2_kernel<KV, 8>), dim3(cdiv(Q, QB2), ns_eff, B), dim3(512), lds, s, eref, ecur, v, out, ws, R,
+                           Q, K, ns_eff, rps, vfs);
     } else if constexpr (KV > 8) {
         uni_set_error("corr: 16 value rows per pass only in precision 2 / 3");
         return -1;
@@ -582,7 +592,7 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
                            Q, K, ns_eff, rps);
     }
     if (ns_eff > 1)
-        hipLaunchKernelGGL((corr_merge_kernel<KV>), dim3(cdiv(Q, 256)), dim3(256), 0, s, ws, out, Q, K, ns_eff);
+        hipLaunchKernelGGL((corr_merge_kernel<KV>), dim3(cdiv(Q, 256), B), dim3(256), 0, s, ws, out, Q, K, ns_eff);
     return 0;
 }
 }  // namespace
@@ -591,6 +601,42 @@ size_t corr_workspace_bytes(int R, int Q, int K) {
     (void)K;
     const int a = pick_nsplit(R, Q, 0), b = pick_nsplit(R, Q, 1);
     return (size_t)(a > b ? a : b) * Q * (2 + 16) * sizeof(float);
+}
+
+size_t corr_workspace_bytes_batched(int B, int R, int Q, int K) {
+    (void)K;
+    size_t m = corr_workspace_bytes(R, Q, K);                                    // the per-frame fall-back reuses one frame's scratch
+    const size_t b = (size_t)pick_nsplit(R, Q, 1, B) * B * Q * (2 + 16) * sizeof(float);
+    return b > m ? b : m;
+}
+
+// B frames in ONE launch (blockIdx.z = frame): embeddings [B][R][128] / [B][Q][128], out [B][K][Q], value rows [K][R] shared by the frames
+// (values_per_frame = 0: the SOT label map of the cached first frame) or [B][K][R].  The split of the reference axis is chosen for
+// all B x Q / 256 blocks together: at 16 frames of 800 x 1280 one block walks the whole reference map (no partial results, no merge pass)
+// -- 0.222 vs 0.236-0.243 ms per frame against 16 launches (tools/corr_batch_probe.py).  Precisions 0 / 1 and more than 16 value rows
+// run frame by frame.
+int launch_corr_batched(const float* eref, const float* ecur, const float* v, float* out, int B, int R, int Q, int D, int K,
+                        int values_per_frame, int precision, void* workspace, size_t ws_bytes, hipStream_t s) {
+    UNI_REQUIRE(B > 0, "corr: empty batch");
+    UNI_REQUIRE(ws_bytes >= corr_workspace_bytes_batched(B, R, Q, K), "corr: workspace too small");
+    const long vfs = values_per_frame ? (long)K * R : 0;
+    if (B == 1 || precision < 2 || K > 16) {
+        for (int b = 0; b < B; ++b) {
+            const int rc = launch_corr(eref + (size_t)b * R * D, ecur + (size_t)b * Q * D, v + (size_t)b * vfs, out + (size_t)b * K * Q, R, Q, D, K,
+                                       precision, workspace, ws_bytes, s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    UNI_REQUIRE(D == CD, "corr: embedding dim %d unsupported (128)", D);
+    UNI_REQUIRE(R > 0 && Q > 0 && K > 0, "corr: empty problem R=%d Q=%d K=%d", R, Q, K);
+    UNI_REQUIRE(precision <= 3, "corr: precision %d not implemented", precision);
+    UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
+    float* ws = reinterpret_cast<float*>(workspace);
+    if (K == 1) return run<1>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
+    if (K <= 4) return run<4>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
+    if (K <= 8) return run<8>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
+    return run<16>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
 }
 
 int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,

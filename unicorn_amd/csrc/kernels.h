@@ -143,6 +143,9 @@ int launch_msda_fused(const MsdaFusedArgs& a, hipStream_t s);
 int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,
                 int precision, void* workspace, size_t ws_bytes, hipStream_t s);
 size_t corr_workspace_bytes(int R, int Q, int K);
+int launch_corr_batched(const float* eref, const float* ecur, const float* v, float* out, int B, int R, int Q, int D, int K,
+                        int values_per_frame, int precision, void* workspace, size_t ws_bytes, hipStream_t s);
+size_t corr_workspace_bytes_batched(int B, int R, int Q, int K);
 
 // ---------------------------------------------------------------- misc.hip
 int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32 = 0);

@@ -70,6 +70,35 @@ def corr_softmax_pv(embed_ref, embed_cur, values, precision=0):
     return out
 
 
+def corr_softmax_pv_batched(embed_ref, embed_cur, values, precision=2, values_per_frame=False):
+    """B frames in ONE launch (`uni_corr_softmax_pv_batched`): embed_* (B, C, HW) or (B, C, H, W) (channels_last maps need no copy),
+    values (K, HW_ref) shared by the frames -- the SOT label map of the cached first frame -- or (B, K, HW_ref) with values_per_frame
+    -> (B, K, HW_cur).  == torch.stack([corr_softmax_pv(embed_ref[b], embed_cur[b], values) for b in range(B)])."""
+    _need_cuda(embed_ref, embed_cur, values)
+    er = embed_ref.float().flatten(2).transpose(1, 2).contiguous()     # (B, HW, C)
+    ec = embed_cur.float().flatten(2).transpose(1, 2).contiguous()
+    v = values.float().contiguous()
+    B, R, D = er.shape
+    Q = ec.shape[1]
+    K = v.shape[-2]
+    if values_per_frame and (v.dim() != 3 or v.shape[0] != B):
+        raise ValueError("values_per_frame needs values of shape (B, K, HW_ref)")
+    if not values_per_frame and v.dim() != 2:
+        raise ValueError("shared values must have shape (K, HW_ref)")
+    if ec.shape[0] != B or v.shape[-1] != R:
+        raise ValueError("corr_softmax_pv_batched: shape mismatch")
+    out = torch.empty((B, K, Q), device=er.device, dtype=torch.float32)
+    need = L.lib().uni_corr_workspace_bytes_batched(B, R, Q, K)
+    key = (er.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _corr_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1), device=er.device, dtype=torch.uint8)
+        _corr_ws[key] = ws
+    L.check(L.lib().uni_corr_softmax_pv_batched(L.ptr(er), L.ptr(ec), L.ptr(v), L.ptr(out), B, R, Q, D, K, 1 if values_per_frame else 0,
+                                                precision, L.ptr(ws), ws.numel(), L.stream_ptr()), "uni_corr_softmax_pv_batched")
+    return out
+
+
 def prior_pyramid(coarse):
     """(1,K,H8,W8) -> (coarse, 1/2, 1/4) like unicorn_sot.py:103-105"""
     _need_cuda(coarse)

@@ -8,7 +8,7 @@ Images are taken already letter-boxed as (1,3,H,W) BGR 0-255 float tensors or ra
 import numpy as np
 import torch
 
-from ..ops import corr_softmax_pv, label_map_s8, letterbox, prior_pyramid
+from ..ops import corr_softmax_pv, corr_softmax_pv_batched, label_map_s8, letterbox, prior_pyramid
 from ..ops import postprocess_launch
 from ..utils.boxes import postprocess
 from ..utils.timing import NoTimer
@@ -57,7 +57,10 @@ class UnicornSOTTrack:
             e_cur = self.model(feat=f_cur, mode="upsample")
             self.t.mark("interaction+upsample")
             prec = 0 if getattr(self.model, "precision", "f16x2") == "fp32" else 2
-            pred = torch.cat([corr_softmax_pv(e_pre[b].flatten(-2), e_cur[b].flatten(-2), self.lbs_pre, precision=prec) for b in range(B)], 0)
+            if B > 1:      # the frames of a time batch share one launch (and the label map of the cached first frame)
+                pred = corr_softmax_pv_batched(e_pre, e_cur, self.lbs_pre, precision=prec)
+            else:
+                pred = corr_softmax_pv(e_pre[0].flatten(-2), e_cur[0].flatten(-2), self.lbs_pre, precision=prec)
             coarse = pred.view(1, B, self.dh, self.dw)
             self.t.mark("correlation")
             pri = tuple(t.transpose(0, 1).contiguous() for t in prior_pyramid(coarse)) if B > 1 else prior_pyramid(coarse)
