@@ -307,35 +307,55 @@ __global__ __launch_bounds__(512) void dwconv7_ln_kernel(DwLnArgs p, int S, int 
             const float* base = p.x + (img0 + (size_t)(y - 3) * p.W + (x0 - 3)) * C + cg * 4;
             const size_t rstride = (size_t)p.W * C;
             dw_load_row_interior<IN>(cur, base, C);
-#pragma unroll 1
-            for (int ky = 0; ky < 7; ++ky) {
-                if (ky < 6) dw_load_row_interior<IN>(nxt, base + (size_t)(ky + 1) * rstride, C);
+            // rows 0..5 with the prefetch of the next row, row 6 peeled (a conditional prefetch makes the wait counts conservative: the
+            // first FMA then waits for the prefetch it should run beside).  The taps of a row are requested BEFORE the next input row:
+            // loads return in order.
+            auto taps = [&](f32x4 (&w)[7], int ky) __attribute__((always_inline)) {
                 const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+                for (int kx = 0; kx < 7; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+            };
+            auto mac = [&](const f32x4 (&w)[7]) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int o = 0; o < PX; ++o) {
+                for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[e], cur[o + kx][e], acc[o][e]);
-                    }
-                }
+                    for (int o = 0; o < PX; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[kx][e], cur[o + kx][e], acc[o][e]);
+            };
+#pragma unroll 1
+            for (int ky = 0; ky < 6; ++ky) {
+                f32x4 w[7];
+                taps(w, ky);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_load_row_interior<IN>(nxt, base + (size_t)(ky + 1) * rstride, C);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(w);
 #pragma unroll
                 for (int j = 0; j < IN; ++j) cur[j] = nxt[j];
+            }
+            {
+                f32x4 w[7];
+                taps(w, 6);
+                mac(w);
             }
         } else {
             dw_load_row<IN>(cur, p, img0, y - 3, x0, cg);
 #pragma unroll 1
             for (int ky = 0; ky < 7; ++ky) {
-                if (ky < 6) dw_load_row<IN>(nxt, p, img0, y + ky - 2, x0, cg);      // prefetch the next input row
                 const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
+                f32x4 w[7];
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ky < 6) dw_load_row<IN>(nxt, p, img0, y + ky - 2, x0, cg);      // prefetch the next input row
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) {
-                    f32x4 w = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
 #pragma unroll
                     for (int o = 0; o < PX; ++o) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[e], cur[o + kx][e], acc[o][e]);
+                        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(w[kx][e], cur[o + kx][e], acc[o][e]);
                     }
                 }
 #pragma unroll
