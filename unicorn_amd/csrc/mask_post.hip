@@ -93,11 +93,6 @@ __global__ __launch_bounds__(256) void overlap_free_kernel(const unsigned char* 
 // Pass 1 counts the starts per tile of RLE_TILE elements, pass 2 scans the tile counts (one block per mask), pass 3 writes
 // the start positions, pass 4 turns them into counts and per-run string lengths, pass 5 scans those and pass 6 writes chars.
 constexpr int RLE_TILE = 2048;     // elements per block (256 threads x 8)
-__device__ __forceinline__ unsigned char rle_elem(const unsigned char* m, int h, int w, long j) {
-    if (j < 0) return 0;
-    const int x = (int)(j / h), y = (int)(j - (long)x * h);
-    return m[(size_t)y * w + x] ? 1 : 0;
-}
 __device__ int block_excl_scan(int v, int* total, int* sh /* [256 / 64 + 1] */) {     // 256-thread exclusive scan
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int inc = v;
@@ -114,16 +109,62 @@ __device__ int block_excl_scan(int v, int* total, int* sh /* [256 / 64 + 1] */) 
     __syncthreads();
     return base + inc - v;
 }
-__global__ __launch_bounds__(256) void rle_count_kernel(const unsigned char* __restrict__ in, int h, int w, int ntiles, int* __restrict__ tile_cnt) {
+// pycocotools walks a mask COLUMN-major: element j = (x = j / h, y = j % h).  Read straight from the (h, w) bytes every element is its own
+// cache line (169 us per pass for the masks of a 1080p MOTS frame); the encoder therefore first writes a binarised TRANSPOSED copy (w, h) into
+// its workspace -- 64 x 128 tiles through LDS, 4-byte accesses on both sides -- and the two passes over the elements read it linearly, 8 bytes
+// per thread (28 + 14 + 19 us instead of 169 + 168).
+constexpr int TRX = 64, TRY = 128;
+__global__ __launch_bounds__(256) void rle_transpose_kernel(const unsigned char* __restrict__ in, int h, int w, size_t pitch, unsigned char* __restrict__ out) {
+    __shared__ unsigned char tile[TRY][TRX + 4];                 // +4: rows 68 bytes apart (bank spread for the column reads)
+    const int n = blockIdx.z, x0 = blockIdx.x * TRX, y0 = blockIdx.y * TRY;
+    const unsigned char* m = in + (size_t)n * h * w;
+    unsigned char* o = out + (size_t)n * pitch;
+    const bool al = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0;
+    for (int u = threadIdx.x; u < TRY * (TRX / 4); u += 256) {   // 4 bytes along x per access
+        const int yy = u / (TRX / 4), xx = (u - yy * (TRX / 4)) * 4;
+        const int y = y0 + yy, x = x0 + xx;
+        unsigned char b[4] = {0, 0, 0, 0};
+        if (y < h) {
+            if (al && x + 3 < w) { const uchar4 q = *reinterpret_cast<const uchar4*>(m + (size_t)y * w + x); b[0] = q.x; b[1] = q.y; b[2] = q.z; b[3] = q.w; }
+            else for (int e = 0; e < 4; ++e) if (x + e < w) b[e] = m[(size_t)y * w + x + e];
+        }
+        for (int e = 0; e < 4; ++e) tile[yy][xx + e] = b[e] ? 1 : 0;
+    }
+    __syncthreads();
+    const bool alo = (h & 3) == 0 && (pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+    for (int u = threadIdx.x; u < TRX * (TRY / 4); u += 256) {   // 4 bytes along y per access
+        const int xx = u / (TRY / 4), yy = (u - xx * (TRY / 4)) * 4;
+        const int x = x0 + xx, y = y0 + yy;
+        if (x >= w || y >= h) continue;
+        unsigned char* dst = o + (size_t)x * h + y;
+        if (alo && y + 3 < h) *reinterpret_cast<uchar4*>(dst) = make_uchar4(tile[yy][xx], tile[yy + 1][xx], tile[yy + 2][xx], tile[yy + 3][xx]);
+        else for (int e = 0; e < 4 && y + e < h; ++e) dst[e] = tile[yy + e][xx];
+    }
+}
+// 8 consecutive elements of the transposed copy (positions past the end read as the last element: no start is counted there)
+__device__ __forceinline__ void rle_load8(const unsigned char* mt, long a, long j0, unsigned char (&t)[8], unsigned char& prev) {
+    prev = j0 > 0 ? mt[j0 - 1] : 0;
+    if (j0 + 8 <= a && ((reinterpret_cast<uintptr_t>(mt) + (size_t)j0) & 7) == 0) {
+        const unsigned long long q = *reinterpret_cast<const unsigned long long*>(mt + j0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (unsigned char)((q >> (8 * e)) & 0xff);
+    } else {
+        unsigned char last = prev;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { if (j0 + e < a) last = mt[j0 + e]; t[e] = last; }
+    }
+}
+__global__ __launch_bounds__(256) void rle_count_kernel(const unsigned char* __restrict__ mt_all, size_t pitch, long a, int ntiles, int* __restrict__ tile_cnt) {
     __shared__ int sh[5];
     const int n = blockIdx.y, tile = blockIdx.x;
-    const unsigned char* m = in + (size_t)n * h * w;
-    const long a = (long)h * w, j0 = (long)tile * RLE_TILE + threadIdx.x * 8;
+    const unsigned char* mt = mt_all + (size_t)n * pitch;
+    const long j0 = (long)tile * RLE_TILE + threadIdx.x * 8;
     int c = 0;
-    unsigned char prev = rle_elem(m, h, w, j0 - 1);
-    for (int e = 0; e < 8; ++e) {
-        const long j = j0 + e;
-        if (j < a) { const unsigned char t = rle_elem(m, h, w, j); c += t != prev; prev = t; }
+    if (j0 < a) {
+        unsigned char t[8], prev;
+        rle_load8(mt, a, j0, t, prev);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { c += t[e] != prev; prev = t[e]; }
     }
     int total;
     (void)block_excl_scan(c, &total, sh);
@@ -149,21 +190,22 @@ __global__ __launch_bounds__(256) void rle_scan_kernel(int* __restrict__ v, int 
     }
     if (threadIdx.x == 0 && totals) totals[blockIdx.x] = carry;
 }
-__global__ __launch_bounds__(256) void rle_starts_kernel(const unsigned char* __restrict__ in, int h, int w, int ntiles, const int* __restrict__ tile_off,
+__global__ __launch_bounds__(256) void rle_starts_kernel(const unsigned char* __restrict__ mt_all, size_t pitch, long a, int ntiles, const int* __restrict__ tile_off,
                                                          int max_runs, int* __restrict__ starts) {
     __shared__ int sh[5];
     const int n = blockIdx.y, tile = blockIdx.x;
-    const unsigned char* m = in + (size_t)n * h * w;
-    const long a = (long)h * w, j0 = (long)tile * RLE_TILE + threadIdx.x * 8;
-    unsigned char t[8];
-    unsigned char prev = rle_elem(m, h, w, j0 - 1);
+    const unsigned char* mt = mt_all + (size_t)n * pitch;
+    const long j0 = (long)tile * RLE_TILE + threadIdx.x * 8;
     int c = 0;
     unsigned flags = 0;
-    for (int e = 0; e < 8; ++e) {
-        const long j = j0 + e;
-        t[e] = j < a ? rle_elem(m, h, w, j) : prev;
-        if (j < a && t[e] != prev) { flags |= 1u << e; ++c; }
-        prev = t[e];
+    if (j0 < a) {
+        unsigned char t[8], prev;
+        rle_load8(mt, a, j0, t, prev);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (t[e] != prev) { flags |= 1u << e; ++c; }      // (positions past the end repeat the last element: never a start)
+            prev = t[e];
+        }
     }
     int off = tile_off[(size_t)n * ntiles + tile] + block_excl_scan(c, nullptr, sh);
     for (int e = 0; e < 8; ++e)
@@ -241,9 +283,13 @@ int launch_overlap_free(const unsigned char* in, int N, int H, int W, unsigned c
     hipLaunchKernelGGL(overlap_free_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, s, in, N, hw, out);
     return 0;
 }
-size_t rle_workspace_bytes(int N, int H, int W, int max_runs) {
+static size_t rle_pitch(int H, int W) { return ((size_t)H * W + 15) / 16 * 16; }      // bytes per transposed mask (16-byte aligned: 8-byte reads)
+static size_t rle_int_bytes(int N, int H, int W, int max_runs) {                        // the integer arrays, rounded to 16 bytes
     const size_t ntiles = ((size_t)H * W + RLE_TILE - 1) / RLE_TILE;
-    return ((size_t)N * (ntiles + (size_t)max_runs + 2 * ((size_t)max_runs + 1) + 2)) * sizeof(int) + 256;
+    return (((size_t)N * (ntiles + (size_t)max_runs + 2 * ((size_t)max_runs + 1) + 2)) * sizeof(int) + 256 + 15) / 16 * 16;
+}
+size_t rle_workspace_bytes(int N, int H, int W, int max_runs) {
+    return rle_int_bytes(N, H, W, max_runs) + (size_t)N * rle_pitch(H, W) + 16;      // + the transposed binarised copy of the masks
 }
 __global__ void rle_finalize_kernel(const int* __restrict__ nstart, int N, int max_runs, int max_chars, int* __restrict__ out_len,
                                     int* __restrict__ n_runs) {
@@ -266,10 +312,13 @@ int launch_rle_encode(const unsigned char* masks, int N, int H, int W, int max_r
     int* starts = tile_cnt + (size_t)N * ntiles;                 // [N][max_runs] run start positions (column-major element index)
     int* lens = starts + (size_t)N * max_runs;                   // [N][max_runs + 1] chars per run -> exclusive offsets
     int* nstart = lens + (size_t)N * (max_runs + 1);             // [N]
+    const size_t pitch = rle_pitch(H, W);
+    unsigned char* mt = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws) + rle_int_bytes(N, H, W, max_runs) + 15) & ~uintptr_t(15));   // [N][pitch] transposed copy
     UNI_CHECK_HIP(hipMemsetAsync(lens, 0, (size_t)N * (max_runs + 1) * sizeof(int), s));
-    hipLaunchKernelGGL(rle_count_kernel, dim3(ntiles, N), dim3(256), 0, s, masks, H, W, ntiles, tile_cnt);
+    hipLaunchKernelGGL(rle_transpose_kernel, dim3(cdiv(W, TRX), cdiv(H, TRY), N), dim3(256), 0, s, masks, H, W, pitch, mt);
+    hipLaunchKernelGGL(rle_count_kernel, dim3(ntiles, N), dim3(256), 0, s, mt, pitch, a, ntiles, tile_cnt);
     hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, tile_cnt, ntiles, ntiles, nstart);
-    hipLaunchKernelGGL(rle_starts_kernel, dim3(ntiles, N), dim3(256), 0, s, masks, H, W, ntiles, tile_cnt, max_runs, starts);
+    hipLaunchKernelGGL(rle_starts_kernel, dim3(ntiles, N), dim3(256), 0, s, mt, pitch, a, ntiles, tile_cnt, max_runs, starts);
     hipLaunchKernelGGL(rle_len_kernel, dim3(cdiv(max_runs + 1, 256), N), dim3(256), 0, s, starts, nstart, a, max_runs, lens, counts);
     hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, lens, max_runs + 1, max_runs + 1, out_len);
     hipLaunchKernelGGL(rle_write_kernel, dim3(cdiv(max_runs + 1, 256), N), dim3(256), 0, s, starts, nstart, a, max_runs, lens, max_chars, out_chars);
