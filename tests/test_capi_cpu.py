@@ -79,12 +79,14 @@ def test_pack_weight_h2_matches_numpy():
 def test_fails_loudly_without_gpu():
     from unicorn_amd import _lib
     from unicorn_amd.models import Unicorn
-    from unicorn_amd.ops import corr_softmax_pv
+    from unicorn_amd.ops import corr_softmax_pv, corr_softmax_pv_batched
     m = Unicorn("unicorn_track_tiny")
     with pytest.raises(_lib.UnicornHipError):
         m.cuda()
     with pytest.raises(_lib.UnicornHipError):
         corr_softmax_pv(torch.zeros(128, 4), torch.zeros(128, 4), torch.zeros(1, 4))
+    with pytest.raises(_lib.UnicornHipError):
+        corr_softmax_pv_batched(torch.zeros(2, 128, 4), torch.zeros(2, 128, 4), torch.zeros(1, 4))
     with pytest.raises(_lib.UnicornHipError):
         m(imgs=torch.zeros(1, 3, 32, 32), mode="backbone")
 
