@@ -216,5 +216,6 @@ if __name__ == "__main__":
     run_sot("unicorn_track_large", 320, 320)
     run_sot("unicorn_track_large_mask", 320, 320)
     run_sot("unicorn_track_large_mot_challenge", 320, 320)
+    run_sot("unicorn_track_tiny_mask", 320, 512)       # non-square (H / W = 0.625 like 800 x 1280): row / column order of pos-embed, reference points, grids
     run_vos("unicorn_track_tiny_mask", 320, 320)
     run_vos("unicorn_track_large_mask", 320, 320)

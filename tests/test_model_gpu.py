@@ -94,17 +94,18 @@ def hip_sot_step(m, cfg, frames, box):
 EXACT = ("fp32", "f16x2")      # precision modes that must meet the north_star bar
 
 
-GOLDEN_CASES = [(e, p) for e in ("unicorn_track_tiny", "unicorn_track_tiny_mask") for p in ("fp32", "f16x2", "bf16")] + \
-    [(e, "f16x2") for e in ("unicorn_track_large", "unicorn_track_large_mask", "unicorn_track_large_mot_challenge")]
+GOLDEN_CASES = [(e, p, 320, 320) for e in ("unicorn_track_tiny", "unicorn_track_tiny_mask") for p in ("fp32", "f16x2", "bf16")] + \
+    [(e, "f16x2", 320, 320) for e in ("unicorn_track_large", "unicorn_track_large_mask", "unicorn_track_large_mot_challenge")] + \
+    [("unicorn_track_tiny_mask", "f16x2", 320, 512)]      # non-square golden of the real reference (the 800 x 1280 aspect)
 
 
-@pytest.mark.parametrize("exp,precision", GOLDEN_CASES)
-def test_tiny_320_vs_reference_golden(exp, precision, golden_dir):
+@pytest.mark.parametrize("exp,precision,H,W", GOLDEN_CASES)
+def test_tiny_320_vs_reference_golden(exp, precision, H, W, golden_dir):
     """BASELINE.json configs[0] shapes; expected values come from the real reference (tests/golden/make_golden.py): the tiny
-    models in all three precisions, the headline `unicorn_track_large` family in the headline precision."""
-    g = np.load(os.path.join(golden_dir, "%s_320x320.npz" % exp))
+    models in all three precisions, the headline `unicorn_track_large` family in the headline precision, and one non-square map."""
+    g = np.load(os.path.join(golden_dir, "%s_%dx%d.npz" % (exp, H, W)))
     m, cfg, P = build(exp, precision)
-    frames, box = synth.synth_clip(320, 320, 2, seed=1)
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
     r = hip_sot_step(m, cfg, frames, box)
     met = {}
     assert np.array_equal(sample(r["lbs"]), g["lbs_pre"])
@@ -131,7 +132,7 @@ def test_tiny_320_vs_reference_golden(exp, precision, golden_dir):
             met[n] = rel_l2(sample(t), g[n])
         assert np.allclose(sample(r["head"][1]), g["locations"])
         assert np.array_equal(sample(r["head"][3]), g["fpn_levels"])
-    METRICS["golden_%s_%s" % (exp, precision)] = met
+    METRICS["golden_%s_%s%s" % (exp, precision, "" if (H, W) == (320, 320) else "_%dx%d" % (H, W))] = met
     _dump()
     assert met["seq_pos"] < 1e-5
     feat_tol, prior_tol = (1e-4, 1e-4) if precision in EXACT else (5e-2, 2e-2)

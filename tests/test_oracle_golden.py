@@ -50,17 +50,18 @@ def test_msda_known_answer(golden_dir):
         assert torch.allclose(out, ref, rtol=1e-4, atol=1e-6), (out - ref).abs().max()
 
 
-@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask", "unicorn_track_large",
-                                 "unicorn_track_large_mask", "unicorn_track_large_mot_challenge"])
-def test_sot_step_matches_reference(exp, golden_dir):
+@pytest.mark.parametrize("exp,H,W", [("unicorn_track_tiny", 320, 320), ("unicorn_track_tiny_mask", 320, 320), ("unicorn_track_large", 320, 320),
+                                     ("unicorn_track_large_mask", 320, 320), ("unicorn_track_large_mot_challenge", 320, 320),
+                                     ("unicorn_track_tiny_mask", 320, 512)])      # non-square: the 800 x 1280 aspect (H / W = 0.625)
+def test_sot_step_matches_reference(exp, H, W, golden_dir):
     """BASELINE.json configs[0]: tiny, 2-frame 320x320 synthetic clip, CPU -- and the same clip through the REAL reference's
     headline model (`unicorn_track_large`, depths [3,3,27,3] / dims [192..1536], convnext.py:198-211), its mask variant and the
     num_classes = 1 MOT-challenge head (exps/default/unicorn_track_large_mot_challenge.py:18)."""
     torch.set_num_threads(8)
-    g = np.load(os.path.join(golden_dir, "%s_320x320.npz" % exp))
+    g = np.load(os.path.join(golden_dir, "%s_%dx%d.npz" % (exp, H, W)))
     cfg = uo.CONFIGS[exp]
     P = synth.synth_state_dict(cfg)
-    frames, box = synth.synth_clip(320, 320, 2, seed=1)
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
     with torch.no_grad():
         st = uo.sot_init(P, cfg, frames[0], box)
         check(g, "lbs_pre", st["lbs_pre"])
