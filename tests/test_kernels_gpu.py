@@ -504,6 +504,11 @@ def test_prior_pyramid_label_map(L):
         ref = uo.label_map_s8(torch.tensor(box), 800, 1280)
         got = label_map_s8(box, 800, 1280, "cuda")
         assert torch.equal(got.cpu(), ref), box
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "labelmap_ref.npz"))      # the reference's own get_label_map
+    for tag in ("a", "b"):
+        H, W = (int(v) for v in gold["hw_" + tag])
+        for b, ref in zip(gold["boxes"], gold["lbs_" + tag]):
+            assert np.array_equal(label_map_s8([float(v) for v in b], H, W, "cuda")[0].cpu().numpy(), ref), (tag, b)
 
 
 def test_sample_embeddings(L):

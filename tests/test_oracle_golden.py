@@ -169,3 +169,14 @@ def test_sample_instance_embeddings_matches_reference_lines(golden_dir):
     for tag in ("a", "b"):
         got = uo.sample_instance_embeddings(torch.from_numpy(g["embed_" + tag]), torch.from_numpy(g["boxes_" + tag]))
         assert torch.allclose(got, torch.from_numpy(g["feats_" + tag]), atol=1e-6), tag
+
+
+def test_label_map_matches_reference_function(golden_dir):
+    """`get_label_map` + the driver's 1/8 bilinear down-sampling (unicorn_sot.py:52-53,128-139): the golden maps come from exec-ing
+    the reference function (tests/golden/make_golden_labelmap.py) on half-integer, clipped, empty and inverted boxes."""
+    g = np.load(os.path.join(golden_dir, "labelmap_ref.npz"))
+    for tag in ("a", "b"):
+        H, W = (int(v) for v in g["hw_" + tag])
+        for b, ref in zip(g["boxes"], g["lbs_" + tag]):
+            got = uo.label_map_s8(torch.from_numpy(b), H, W)[0].numpy()
+            assert np.array_equal(got, ref), (tag, b)
