@@ -916,6 +916,8 @@ def main():
             "single_frame": single,
             "parity": parity, "roofline": roof, "cpu_baseline": cpu, "modes": modes, "configs": configs, "kernels": extra,
             "rank_errors": rank_errors,
+            # third-party arithmetic on the path that no reference-owned vector pins (absent offline: SURVEY.md 8c); also inside `parity`
+            "parity_unpinned": ["cv2.resize", "torchvision.nms", "pycocotools.rle", "lap.lapjv", "cython_bbox.bbox_overlaps"],
         }
         print(json.dumps(line))
     if dist is not None:
