@@ -54,7 +54,7 @@ inline float iou(const Box& a, const Box& b) {
 // but the loop nest puts j innermost over a transposed copy of y, so the compiler vectorises ACROSS memory rows: same bits on every
 // machine and vector width, ~10x the speed of the scalar chains (which took ~3 ms per frame for 100 detections x 250 memory rows x 256
 // dims: 60 % of the evaluate_omni association stage).
-__attribute__((target_clones("avx2", "default")))
+__attribute__((target_clones("avx512f", "avx2", "default")))
 void dot_matrix(const float* x, int m, const float* y, int M, int dim, float* f) {
     constexpr int JB = 32;                                   // memory rows per block: [d][JB] image of 128 B x dim stays in L1 across all i
     const int nb = (M + JB - 1) / JB;
@@ -93,6 +93,62 @@ void dot_matrix(const float* x, int m, const float* y, int M, int dim, float* f)
     }
 }
 // squared norms of the rows of a [rows][dim] matrix (ascending-d chain, like dot_matrix)
+// exp(x) for x <= 0 without a libm call, so that the loops over a similarity row / column vectorise (std::exp was 70 k scalar calls = 1.4 of the
+// 1.6 ms of a 200-detection frame): n = round(x log2 e) through the 1.5 * 2^23 trick, r = x - n ln 2 in two pieces, the degree-6 polynomial of the
+// Cephes expf, 2^n through the exponent bits.  Relative error < 2e-7 (torch's own softmax uses a vectorised exp of the same class, not libm's).
+static inline float exp_neg(float x) {
+    x = x < -87.f ? -87.f : x;
+    const float t = x * 1.44269504088896341f;
+    const float n = (t + 12582912.f) - 12582912.f;
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * (r * r) + r + 1.f;
+    int32_t bits = ((int32_t)n + 127) << 23;
+    float sc;
+    std::memcpy(&sc, &bits, 4);
+    return p * sc;
+}
+
+// scores = softmax over dim 1 (d2t) and, for bisoftmax, the mean with the softmax over dim 0 (t2d): exp(x - max) / sum
+// (quasi_dense_embed_tracker.py:166-173).  f is overwritten.  Multi-versioned like dot_matrix: every lane does the same operations in the same
+// order at any vector width (no contraction), so the clones give identical results.
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void softmax_scores(float* f, float* sc, int m, int M, bool bi) {
+    for (int i = 0; i < m; ++i) {
+        const float* fi = f + (size_t)i * M;
+        float* si = sc + (size_t)i * M;
+        float mx = -INFINITY, s = 0.f;
+        for (int j = 0; j < M; ++j) mx = std::max(mx, fi[j]);
+        for (int j = 0; j < M; ++j) si[j] = exp_neg(fi[j] - mx);          // (vectorises: no reduction in this loop)
+        for (int j = 0; j < M; ++j) s += si[j];                              // sum in index order
+        for (int j = 0; j < M; ++j) si[j] /= s;
+    }
+    if (!bi) return;
+    // the column softmax walks the matrix ROW by row (j innermost: contiguous, vectorised); every column still takes its maximum and its
+    // sum over i in ascending order
+    std::vector<float> cmx(M, -INFINITY), cs(M, 0.f);
+    for (int i = 0; i < m; ++i) {
+        const float* fi = f + (size_t)i * M;
+        for (int j = 0; j < M; ++j) cmx[j] = std::max(cmx[j], fi[j]);
+    }
+    for (int i = 0; i < m; ++i) {
+        float* fi = f + (size_t)i * M;
+        for (int j = 0; j < M; ++j) fi[j] = exp_neg(fi[j] - cmx[j]);
+        for (int j = 0; j < M; ++j) cs[j] += fi[j];
+    }
+    for (int i = 0; i < m; ++i) {
+        const float* fi = f + (size_t)i * M;
+        float* si = sc + (size_t)i * M;
+        for (int j = 0; j < M; ++j) si[j] = (si[j] + fi[j] / cs[j]) / 2;
+    }
+}
+
 void dot_rows(const float* a, int rows, int dim, float* out) {
     for (int i = 0; i < rows; ++i) {
         float s = 0.f;
@@ -206,21 +262,7 @@ int uni_qd_match(uni_qd* t, const float* bboxes_in, const int64_t* labels_in, co
             std::vector<float> f((size_t)m * M);
             dot_matrix(X.data(), m, Y.data(), M, dim, f.data());
             // softmax over dim 1 (d2t) and, for bisoftmax, dim 0 (t2d): exp(x - max) / sum  (:166-173)
-            for (int i = 0; i < m; ++i) {
-                float mx = -INFINITY, s = 0.f;
-                for (int j = 0; j < M; ++j) mx = std::max(mx, f[(size_t)i * M + j]);
-                for (int j = 0; j < M; ++j) { float e = std::exp(f[(size_t)i * M + j] - mx); sc[(size_t)i * M + j] = e; s += e; }
-                for (int j = 0; j < M; ++j) sc[(size_t)i * M + j] /= s;
-            }
-            if (c.match_metric == 0) {
-                std::vector<float> col(m);
-                for (int j = 0; j < M; ++j) {
-                    float mx = -INFINITY, s = 0.f;
-                    for (int i = 0; i < m; ++i) mx = std::max(mx, f[(size_t)i * M + j]);
-                    for (int i = 0; i < m; ++i) { col[i] = std::exp(f[(size_t)i * M + j] - mx); s += col[i]; }
-                    for (int i = 0; i < m; ++i) sc[(size_t)i * M + j] = (sc[(size_t)i * M + j] + col[i] / s) / 2;
-                }
-            }
+            softmax_scores(f.data(), sc.data(), m, M, c.match_metric == 0);
         }
         if (c.with_cats)                                                // :182-184
             for (int i = 0; i < m; ++i)
