@@ -158,3 +158,21 @@ def test_byte_native_edges():
     assert [t.track_id for t in out] == [1] and abs(out[0].tlwh[2] * out[0].tlwh[3] - (100 / 0.7407407) * (200 / 0.7407407)) < 60
     with pytest.raises(ValueError):
         trk.update(np.zeros((3, 4), np.float32), (1080, 1920), (800, 1440))
+
+
+def test_native_non_finite_embeddings_are_deterministic():
+    """a NaN / inf embedding row must not reach an int conversion (UB) in the vectorised exp: NaN similarities propagate
+    like std::exp's (the detection matches nothing and starts / keeps its own track), the call succeeds, repeated runs agree."""
+    def run():
+        trk = QuasiDenseEmbedTracker()
+        outs = []
+        for f, (b, l, e) in enumerate(ao.synth_sequence(n_frames=6, n_obj=8, seed=11)):
+            e = e.clone()
+            if f >= 2:
+                e[0] = float("nan")
+                e[1, 3] = float("inf")
+            outs.append(trk.match(b, l, e, f)[2].clone())
+        return outs
+    a, b = run(), run()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert all(x.numel() > 0 for x in a)

@@ -6,10 +6,8 @@ Three precision modes of the same kernels are tested (DESIGN.md "precision"):
   precision="fp32"  exact-fp32 MFMA everywhere: both must meet the north_star bar
         box IoU >= 0.999, mask IoU >= 0.999, embedding cosine within 1e-4 (min over pixels >= 1 - 1e-4),
         feature maps rel-L2 <= 1e-4, propagated prior max-abs <= 1e-4
-  precision="bf16"  benchmark configuration (bf16 MFMA operands, fp32 accumulate / residual / statistics, fp32
-        correlation): embedding cosine within 1e-4 still holds; feature maps rel-L2 <= 5e-2; prior max-abs <= 2e-2.
-        With the synthetic *random* weights the box regressors amplify bf16 rounding (no trained-in smoothness), so
-        box IoU is only guarded loosely here (mean over the top anchors >= 0.75); see DESIGN.md.
+  precision="bf16"  RETIRED secondary mode (bf16 MFMA operands; cannot meet the bar with any weights): one
+        320x320 golden case keeps its kernels exercised (feature maps rel-L2 <= 5e-2, prior max-abs <= 2e-2, finite boxes).
 The measured values are written to gpurun_out/parity_metrics.json."""
 import json
 import os
@@ -94,7 +92,10 @@ def hip_sot_step(m, cfg, frames, box):
 EXACT = ("fp32", "f16x2")      # precision modes that must meet the north_star bar
 
 
-GOLDEN_CASES = [(e, p, 320, 320) for e in ("unicorn_track_tiny", "unicorn_track_tiny_mask") for p in ("fp32", "f16x2", "bf16")] + \
+# bf16 is a RETIRED secondary mode (it cannot meet the north_star bar with any weights): ONE golden case keeps its
+# kernels building and finite; the 800x1280 / ragged / batched bf16 runs of rounds 1-4 were dropped from the suite in round 5
+GOLDEN_CASES = [(e, p, 320, 320) for e in ("unicorn_track_tiny", "unicorn_track_tiny_mask") for p in ("fp32", "f16x2")] + \
+    [("unicorn_track_tiny", "bf16", 320, 320)] + \
     [(e, "f16x2", 320, 320) for e in ("unicorn_track_large", "unicorn_track_large_mask", "unicorn_track_large_mot_challenge")] + \
     [("unicorn_track_tiny_mask", "f16x2", 320, 512)]      # non-square golden of the real reference (the 800 x 1280 aspect)
 
@@ -247,13 +248,13 @@ def _assert_bar(met, precision):
         assert met["box_iou_mean_top500"] > 0.75, met
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
 def test_tiny_sot_800x1280_vs_oracle(precision):
     """BASELINE.json configs[1]: unicorn_track_tiny SOT 800x1280 (bf16 backbone + fp32 correlation; and the exact mode)."""
     _assert_bar(_vs_oracle("unicorn_track_tiny", 800, 1280, "tiny_sot_800x1280_" + precision, precision), precision)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
 def test_tiny_mask_ragged_size_vs_oracle(precision):
     """VOS-style head (CondInst) at a non-square size that is ragged for every tile/strip/split: 352x608."""
     _assert_bar(_vs_oracle("unicorn_track_tiny_mask", 352, 608, "tiny_mask_352x608_" + precision, precision), precision)
@@ -262,7 +263,7 @@ def test_tiny_mask_ragged_size_vs_oracle(precision):
 # ------------------------------------------------------------------------------------------------
 # the LARGE models at 800x1280: the configurations bench.py times (BASELINE.json configs[2..3] + the headline)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x2"])
 def test_large_sot_800x1280_vs_oracle(precision):
     """unicorn_track_large SOT step, the bench headline workload: depth-27 stage, C = 1536 tiles, the 256x256 GEMM tiles on
     their real shapes.  f16x2 (the headline precision) must meet the north_star bar; bf16 is held to its documented error
@@ -486,7 +487,7 @@ def test_sot_tracker_and_postprocess_match_oracle_decision():
         assert all(abs(x - y) <= 1 for x, y in zip(a, b)), (got, exp)     # int truncation may flip by 1 px
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
 def test_batched_frames_equal_single_frame_runs(precision):
     """Every stage takes a batch of frames (M = B*H*W rows per kernel): B = 3 must reproduce three B = 1 runs
     (per-sample GroupNorm statistics, conv halos and the head's row remap must not leak across samples).
@@ -792,3 +793,33 @@ def test_saturation_check_mode_counts_planted_outliers():
     assert st2["saturated"] > 0, st2
     assert all(torch.isfinite(t).all() for t in fpn2)
     m2.check_saturation(False)
+
+
+def test_validate_checkpoint_tool_on_the_gpu(tmp_path, capsys):
+    """tools/validate_checkpoint.py end to end: a `{"model": state_dict}` file -> loader rule of the reference ->
+    HIP path in saturation check mode vs the CPU oracle -> parity block + saturation statistics + exit status.  (a) the synthetic
+    weights of a mask model pass; (b) the same file with one pwconv1 scaled by 1e6 saturates f16x2 operands and must FAIL.
+    The CPU half (oracle held to the real reference on a real-reference checkpoint) is tests/test_validate_checkpoint_cpu.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("validate_checkpoint", os.path.join(ROOT, "tools", "validate_checkpoint.py"))
+    vc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vc)
+    name = "unicorn_track_tiny_mask"
+    P = synth.synth_state_dict(uo.CONFIGS[name])
+    good, bad = str(tmp_path / "good.pth"), str(tmp_path / "bad.pth")
+    torch.save({"model": P, "start_epoch": 3}, good)
+    rc = vc.main(["--ckpt", good, "--exp", name, "--size", "320x320", "--frames", "1", "--json", str(tmp_path / "good.json")])
+    capsys.readouterr()
+    rep = json.load(open(str(tmp_path / "good.json")))
+    assert rc == 0 and rep["pass"] and rep["parity"]["pass"], rep
+    assert rep["saturation"]["saturated"] == 0 and rep["saturation"]["scanned"] > 1e6, rep["saturation"]
+    assert rep["parity"]["box_iou_min"] > 0.999 and rep["parity"]["embed_cos_min"] > 1 - 1e-4 and rep["parity"]["mask_iou_min"] > 0.999, rep["parity"]
+    METRICS["validate_checkpoint_tiny_mask"] = rep["parity"]
+    _dump()
+    P2 = {k: v.clone() for k, v in P.items()}
+    P2["backbone.backbone.stages.1.0.pwconv1.weight"] *= 1e6
+    torch.save({"model": P2}, bad)
+    rc = vc.main(["--ckpt", bad, "--exp", name, "--size", "320x320", "--frames", "1", "--json", str(tmp_path / "bad.json")])
+    capsys.readouterr()
+    rep = json.load(open(str(tmp_path / "bad.json")))
+    assert rc == 1 and not rep["pass"] and rep["saturation"]["saturated"] > 0, rep.get("saturation")

@@ -51,3 +51,20 @@ def test_all_frames_with_detections_pair_t_with_t_minus_1():
     assert _refs(m) == [1., 1., 2.]                   # frame 1 of a sequence is its own reference (:1014-1015)
     o._interact(_ticket([4., 5.]), [True, True])
     assert _refs(m) == [3., 4.]
+
+
+def test_reset_starts_a_new_video():
+    """one object across videos must not pair video 2's first frame with video 1's last features
+    (mot_evaluator.py:1014 re-seeds pre_dict at frame_id == 1, :978-979 builds a new tracker)."""
+    import pytest
+    m = _FakeModel()
+    o = OmniMOTFrame(m, "tracker-1", (32, 32))
+    o._interact(_ticket([1., 2.]), [True, True])
+    o.frame_id = 2
+    o.reset(tracker="tracker-2")
+    assert o.pre_dict is None and o.frame_id == 0 and o.tracker == "tracker-2"
+    o._interact(_ticket([7., 8.]), [False, True])
+    assert _refs(m)[1] == 8.                            # own reference again, not 2.
+    o._streaming = True                                # a run_stream generator is alive
+    with pytest.raises(RuntimeError):
+        o.reset()

@@ -304,11 +304,11 @@ int uni_mlp_fused(const void* A, int lda, const void* blob, const float* b1, con
 }
 int uni_cast_h2(const float* x, int ldx, void* out, int ldo, int M, int C, uni_stream_t stream) {
     UNI_REQUIRE(x && out, "cast_h2: NULL argument");
-    API(launch_cast_bf16(x, ldx, reinterpret_cast<bf16*>(out), ldo, M, C, S(stream), FMT_H2));
+    API(launch_cast_operand(x, ldx, reinterpret_cast<bf16*>(out), ldo, M, C, S(stream), FMT_H2));
 }
 int uni_cast_bf16(const float* x, int ldx, uint16_t* out, int ldo, int M, int C, uni_stream_t stream) {
     UNI_REQUIRE(x && out, "cast: NULL argument");
-    API(launch_cast_bf16(x, ldx, reinterpret_cast<bf16*>(out), ldo, M, C, S(stream)));
+    API(launch_cast_operand(x, ldx, reinterpret_cast<bf16*>(out), ldo, M, C, S(stream)));
 }
 int uni_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, float* outF, uint16_t* outB,
                   uni_stream_t stream) {

@@ -96,8 +96,14 @@ void dot_matrix(const float* x, int m, const float* y, int M, int dim, float* f)
 // exp(x) for x <= 0 without a libm call, so that the loops over a similarity row / column vectorise (std::exp was 70 k scalar calls = 1.4 of the
 // 1.6 ms of a 200-detection frame): n = round(x log2 e) through the 1.5 * 2^23 trick, r = x - n ln 2 in two pieces, the degree-6 polynomial of the
 // Cephes expf, 2^n through the exponent bits.  Relative error < 2e-7 (torch's own softmax uses a vectorised exp of the same class, not libm's).
-static inline float exp_neg(float x) {
+// Non-finite input: NaN (a NaN embedding row, or inf - inf when a row / column maximum is +inf) propagates as with std::exp; +inf and
+// anything > 0 is clamped to 0 (-> 1), -inf to -87 (-> ~1.6e-38) -- the integer conversion below never sees a NaN or an out-of-range value
+// (that would be undefined behaviour, and the three clones could then disagree).  Selects, not branches: the loops still vectorise.
+static inline float exp_neg(float x0) {
+    const bool isnan = x0 != x0;
+    float x = isnan ? 0.f : x0;
     x = x < -87.f ? -87.f : x;
+    x = x > 0.f ? 0.f : x;
     const float t = x * 1.44269504088896341f;
     const float n = (t + 12582912.f) - 12582912.f;
     float r = x - n * 0.693359375f;
@@ -112,7 +118,7 @@ static inline float exp_neg(float x) {
     int32_t bits = ((int32_t)n + 127) << 23;
     float sc;
     std::memcpy(&sc, &bits, 4);
-    return p * sc;
+    return isnan ? x0 : p * sc;
 }
 
 // scores = softmax over dim 1 (d2t) and, for bisoftmax, the mean with the softmax over dim 0 (t2d): exp(x - max) / sum

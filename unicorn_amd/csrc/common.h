@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -144,6 +145,20 @@ __device__ __forceinline__ void act_store1(void* base, size_t idx, float a, int 
 static inline int act_elem_bytes(int fmt) { return fmt == FMT_BF16 ? 2 : 4; }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Guard for per-DEVICE one-time setup on the launch path (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property: a
+// `static bool` would leave the second GPU of a process without the opt-in, and an unguarded call is a driver call per launch).
+// first() is true once per (guard, current device); devices >= 64 share bit 63 with a re-set on every call (harmless).
+struct DevOnce {
+    std::atomic<uint64_t> mask{0};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        if (d >= 63) return true;
+        const uint64_t b = 1ull << d;
+        return !(mask.fetch_or(b, std::memory_order_relaxed) & b);
+    }
+};
 
 // error plumbing (api.cpp owns the storage)
 void uni_set_error(const char* fmt, ...);

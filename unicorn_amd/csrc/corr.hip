@@ -566,11 +566,15 @@ int pick_nsplit(int R, int Q, int precision = 0, int B = 1) {
 }
 
 template <int KV>
-int run(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int K, float* ws, int precision,
+int run(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int K, float* ws, size_t ws_bytes, int precision,
         hipStream_t s, int B = 1, long vfs = 0) {
     const int ns = pick_nsplit(R, Q, precision, B);
     int rps = cdiv(cdiv(R, ns), TR) * TR;
     const int ns_eff = cdiv(R, rps);   // every split non-empty
+    // the partial results of THIS launch (real precision, real split) must fit the scratch the caller sized with corr_workspace_bytes*:
+    // checked here, next to the launch, so a later per-precision change of pick_nsplit / corr_slots cannot write past it
+    UNI_REQUIRE(ns_eff == 1 || (size_t)B * ns_eff * Q * (2 + KV) * sizeof(float) <= ws_bytes,
+                "corr: workspace too small for %d splits x %d frames x %d queries (%zu B given)", ns_eff, B, Q, ws_bytes);
     if (precision == 3) {
         size_t lds = (size_t)2 * 2 * TR * CD * sizeof(f16) + (size_t)2 * KV * TR * sizeof(float);
         hipLaunchKernelGGL((corr_h2_kernel<KV, 8, true>), dim3(cdiv(Q, QB2), ns_eff, B), dim3(512), lds, s, eref, ecur, v, out, ws, R,
@@ -599,14 +603,17 @@ int run(const float* eref, const float* ecur, const float* v, float* out, int R,
 
 size_t corr_workspace_bytes(int R, int Q, int K) {
     (void)K;
-    const int a = pick_nsplit(R, Q, 0), b = pick_nsplit(R, Q, 1);
-    return (size_t)(a > b ? a : b) * Q * (2 + 16) * sizeof(float);
+    int m = 1;
+    for (int prec = 0; prec <= 3; ++prec) m = max(m, pick_nsplit(R, Q, prec));      // every precision the launcher accepts
+    return (size_t)m * Q * (2 + 16) * sizeof(float);
 }
 
 size_t corr_workspace_bytes_batched(int B, int R, int Q, int K) {
     (void)K;
     size_t m = corr_workspace_bytes(R, Q, K);                                    // the per-frame fall-back reuses one frame's scratch
-    const size_t b = (size_t)pick_nsplit(R, Q, 1, B) * B * Q * (2 + 16) * sizeof(float);
+    int ns = 1;
+    for (int prec = 2; prec <= 3; ++prec) ns = max(ns, pick_nsplit(R, Q, prec, B));   // the precisions that run batched (others: frame by frame)
+    const size_t b = (size_t)ns * B * Q * (2 + 16) * sizeof(float);
     return b > m ? b : m;
 }
 
@@ -633,10 +640,10 @@ int launch_corr_batched(const float* eref, const float* ecur, const float* v, fl
     UNI_REQUIRE(precision <= 3, "corr: precision %d not implemented", precision);
     UNI_REQUIRE(((uintptr_t)eref & 15) == 0 && ((uintptr_t)ecur & 15) == 0, "corr: embeddings must be 16-B aligned");
     float* ws = reinterpret_cast<float*>(workspace);
-    if (K == 1) return run<1>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
-    if (K <= 4) return run<4>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
-    if (K <= 8) return run<8>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
-    return run<16>(eref, ecur, v, out, R, Q, K, ws, precision, s, B, vfs);
+    if (K == 1) return run<1>(eref, ecur, v, out, R, Q, K, ws, ws_bytes, precision, s, B, vfs);
+    if (K <= 4) return run<4>(eref, ecur, v, out, R, Q, K, ws, ws_bytes, precision, s, B, vfs);
+    if (K <= 8) return run<8>(eref, ecur, v, out, R, Q, K, ws, ws_bytes, precision, s, B, vfs);
+    return run<16>(eref, ecur, v, out, R, Q, K, ws, ws_bytes, precision, s, B, vfs);
 }
 
 int launch_corr(const float* eref, const float* ecur, const float* v, float* out, int R, int Q, int D, int K,
@@ -653,10 +660,10 @@ int launch_corr(const float* eref, const float* ecur, const float* v, float* out
     for (int k0 = 0; k0 < K; k0 += chunk) {
         const int kc = K - k0 < chunk ? K - k0 : chunk;
         int rc;
-        if (kc == 1) rc = run<1>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
-        else if (kc <= 4) rc = run<4>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
-        else if (kc <= 8) rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
-        else rc = run<16>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, precision, s);
+        if (kc == 1) rc = run<1>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, ws_bytes, precision, s);
+        else if (kc <= 4) rc = run<4>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, ws_bytes, precision, s);
+        else if (kc <= 8) rc = run<8>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, ws_bytes, precision, s);
+        else rc = run<16>(eref, ecur, v + (size_t)k0 * R, out + (size_t)k0 * Q, R, Q, kc, ws, ws_bytes, precision, s);
         if (rc) return rc;
     }
     return 0;

@@ -737,7 +737,7 @@ int engine_interaction(uni_ctx* c, const float* feat_ref, const float* pos_ref, 
     const int hw = h * w, C2 = c->cfg.dims[2];
     const size_t L = (size_t)2 * hw * B;                    // tokens over the batch
     ActPtr fb = actalloc(c, L * C2);
-    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_pair(feat_ref, feat_cur, fb, hw, C2, B, s, c->b32); }));     // tokens [B][ref | cur][hw]
+    RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_operand_pair(feat_ref, feat_cur, fb, hw, C2, B, s, c->b32); }));     // tokens [B][ref | cur][hw]
     float* src = wsalloc<float>(c, L * 256);
     ActPtr srcb = actalloc(c, L * 256);
     {   // bottleneck: 1x1 conv + bias -> GroupNorm(32, eps 1e-5) per frame = 2B "samples" of hw rows
@@ -824,7 +824,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     ActPtr fb[3];
     for (int k = 0; k < 3; ++k) {
         fb[k] = actalloc(c, (size_t)Bi * HWk[k] * ch[k]);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(fpn[k], ch[k], fb[k], ch[k], Bi * HWk[k], ch[k], s, c->b32); }));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_operand(fpn[k], ch[k], fb[k], ch[k], Bi * HWk[k], ch[k], s, c->b32); }));
     }
     // The three FPN levels are independent until the decode: run them concurrently (the stride-16/32 levels are
     // far too small to fill 256 CUs on their own).  Level k gets its own stream and a disjoint workspace slice.
@@ -890,7 +890,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         ActPtr hid = actalloc(c, (size_t)M * 1024);
         ActPtr xb = actalloc(c, (size_t)M * 256);
         const int nblk = (int)c->att[k].size();
-        if (nblk == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(x, 256, xb, 256, M, 256, s, c->b32); }));
+        if (nblk == 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_operand(x, 256, xb, 256, M, 256, s, c->b32); }));
         for (int n = 0; n < nblk; ++n) RUN(run_block(c, c->att[k][n], x, Hk[k], Wk[k], t, hid, n == nblk - 1 ? xb : ActPtr(), s));
         ActPtr tw = actalloc(c, (size_t)M * 512);      // [cls | reg] after the first (merged) tower conv
         { Out o; o.B = tw; o.ldb = 512; RUN(run_conv_gn(c, c->tower0[k], c->tower0_gn[k], 32, 1e-3f, ACT_SILU, xb, 256, Hk[k], Wk[k], 1, o, s)); }
@@ -946,7 +946,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
             if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s, Bi); }));
         }
         ActPtr xmb = actalloc(c, (size_t)M8 * 128);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_bf16(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_operand(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
         ActPtr tb[2] = {actalloc(c, (size_t)M8 * 128), actalloc(c, (size_t)M8 * 128)};
         ActPtr cur = xmb;
         for (int i = 0; i < 4; ++i) {

@@ -326,11 +326,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     size_t lds = (size_t)NSTG * (BM + BN) * BK * sizeof(bf16);
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
-    static bool attr_done = false;      // > 64 KiB dynamic LDS needs the opt-in attribute
-    if (!attr_done && lds > 65536) {
+    static DevOnce attr_once;      // > 64 KiB dynamic LDS needs the opt-in attribute
+    if (lds > 65536 && attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>), dim3(grid), dim3(64 * WM * WN), lds, s, a);

@@ -289,11 +289,10 @@ static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
     size_t lds = (size_t)2 * (BM + BN) * 4 * BKE;
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
+    static DevOnce attr_once;
+    if (lds > 65536 && attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     if (a.stats && gy == 1) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), dim3(grid, gy), dim3(64 * WM * WN), lds, s, a);

@@ -250,11 +250,10 @@ static int launch_h2d_cfg(const GemmArgs& a, hipStream_t s) {
     size_t lds = (size_t)NST * (BM + BN) * 128;
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DevOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, true, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     if (a.stats && gy == 1) hipLaunchKernelGGL((gemm_h2d_kernel<WM, WN, TM, TN, CONV, true, NST>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST>), dim3(grid, gy), dim3(64 * WM * WN), lds, s, a);

@@ -148,9 +148,9 @@ int launch_corr_batched(const float* eref, const float* ecur, const float* v, fl
 size_t corr_workspace_bytes_batched(int B, int R, int Q, int K);
 
 // ---------------------------------------------------------------- misc.hip
-int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32 = 0);
+int launch_cast_operand(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32 = 0);
 // x0 / x1 [B][hw][C] fp32 (two frames) -> out [B][2][hw][C] in the operand format (the token layout of the interaction stage), one launch
-int launch_cast_pair(const float* x0, const float* x1, bf16* out, int hw, int C, int B, hipStream_t s, int b32);
+int launch_cast_operand_pair(const float* x0, const float* x1, bf16* out, int hw, int C, int B, hipStream_t s, int b32);
 int launch_pixel_shuffle_bf16(const float* x, bf16* out, int h, int w, int C, hipStream_t s, int b32 = 0, int B = 1);
 int launch_prior_pyramid(const float* p8, float* p16, float* p32, int K, int H8, int W8, hipStream_t s);
 int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, int A2, int W2, int nch, hipStream_t s, int B = 1);

@@ -3,7 +3,9 @@
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-__global__ void cast_bf16_kernel(const float* x, int ldx, bf16* out, int ldo, int M, int C8, int b32) {
+// fp32 rows -> GEMM operand rows in the context's operand format (`b32`: FMT_H2 f16x2 hi/lo groups -- the headline --, FMT_F32 or FMT_BF16);
+// the element type of `out` is nominal (the historical bf16 pointer type of the operand buffers), act_store8 writes the real format
+__global__ void cast_operand_kernel(const float* x, int ldx, bf16* out, int ldo, int M, int C8, int b32) {
     const long total = (long)M * C8;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         int m = (int)(e / C8), c = (int)(e - (long)m * C8) * 8;
@@ -13,16 +15,16 @@ __global__ void cast_bf16_kernel(const float* x, int ldx, bf16* out, int ldo, in
         act_store8(out, (size_t)m * ldo + c, v, b32);
     }
 }
-int launch_cast_bf16(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32) {
-    UNI_REQUIRE(C % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0, "cast_bf16: C=%d ldx=%d ldo=%d", C, ldx, ldo);
+int launch_cast_operand(const float* x, int ldx, bf16* out, int ldo, int M, int C, hipStream_t s, int b32) {
+    UNI_REQUIRE(C % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0, "cast_operand: C=%d ldx=%d ldo=%d", C, ldx, ldo);
     long total = (long)M * (C / 8);
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, x, ldx, out, ldo, M, C / 8, b32);
+    hipLaunchKernelGGL(cast_operand_kernel, dim3(grid), dim3(256), 0, s, x, ldx, out, ldo, M, C / 8, b32);
     return 0;
 }
 
-__global__ void cast_pair_kernel(const float* x0, const float* x1, bf16* out, int hw, int C8, int B, int b32) {
+__global__ void cast_operand_pair_kernel(const float* x0, const float* x1, bf16* out, int hw, int C8, int B, int b32) {
     const long total = (long)2 * B * hw * C8;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long row = e / C8;                       // token over [B][2][hw]
@@ -35,12 +37,12 @@ __global__ void cast_pair_kernel(const float* x0, const float* x1, bf16* out, in
         act_store8(out, (size_t)row * C8 * 8 + c, v, b32);
     }
 }
-int launch_cast_pair(const float* x0, const float* x1, bf16* out, int hw, int C, int B, hipStream_t s, int b32) {
-    UNI_REQUIRE(C % 8 == 0 && hw > 0 && B > 0, "cast_pair: C=%d hw=%d B=%d", C, hw, B);
+int launch_cast_operand_pair(const float* x0, const float* x1, bf16* out, int hw, int C, int B, hipStream_t s, int b32) {
+    UNI_REQUIRE(C % 8 == 0 && hw > 0 && B > 0, "cast_operand_pair: C=%d hw=%d B=%d", C, hw, B);
     const long total = (long)2 * B * hw * (C / 8);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(cast_pair_kernel, dim3(grid), dim3(256), 0, s, x0, x1, out, hw, C / 8, B, b32);
+    hipLaunchKernelGGL(cast_operand_pair_kernel, dim3(grid), dim3(256), 0, s, x0, x1, out, hw, C / 8, B, b32);
     return 0;
 }
 

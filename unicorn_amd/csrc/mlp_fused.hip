@@ -759,13 +759,12 @@ bool mlp_fused16_supported(int C) { return C == 192 || C == 256; }
 template <int C, bool OUTB, int DBG>
 static int launch_mlp16_k(const MlpArgs& a, int grid, hipStream_t s) {
     constexpr int lds = Geo16<C>::LDS;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DevOnce attr_once;
+    if (attr_once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused16_kernel<C, OUTB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             uni_set_error("mlp_fused16: cannot reserve %d bytes of LDS", lds);
             return -1;
         }
-        attr_done = true;
     }
     hipLaunchKernelGGL((mlp_fused16_kernel<C, OUTB, DBG>), dim3(grid), dim3(64 * MW16), lds, s, a);
     return 0;
@@ -774,13 +773,12 @@ static int launch_mlp16_k(const MlpArgs& a, int grid, hipStream_t s) {
 template <int C, int CH, bool OUTB, int DBG>
 static int launch_mlp_k(const MlpArgs& a, int grid, hipStream_t s) {
     constexpr int lds = Geo<C>::LDS;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DevOnce attr_once;
+    if (attr_once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, CH, OUTB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             uni_set_error("mlp_fused: cannot reserve %d bytes of LDS", lds);
             return -1;
         }
-        attr_done = true;
     }
     hipLaunchKernelGGL((mlp_fused_kernel<C, CH, OUTB, DBG>), dim3(grid), dim3(64 * MW), lds, s, a);
     return 0;

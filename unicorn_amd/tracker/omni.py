@@ -4,7 +4,10 @@
 (only if the frame has detections, :1005) interaction(reference frame, current frame) -> ONE embedding upsample -> instance embeddings
 at the box centres (:1024-1034) -> rescale to the original image -> QuasiDenseEmbedTracker.match -> valid ids in ascending order
 (:1049-1055).  The reference frame is the last frame THAT HAD DETECTIONS (`pre_dict = copy.deepcopy(cur_dict)` sits inside the
-`if outputs[0] is not None` branch, :1005-1020); the first frame with detections is its own reference (:1014-1015).
+`if outputs[0] is not None` branch, :1005-1020).  DEVIATION, on purpose: the reference seeds `pre_dict` only `if frame_id == 1`
+(:1014-1015) -- when frame 1 of a video has no detections it interacts the first frame that has some with the LAST VIDEO's features
+(or raises NameError in the first video).  Here the first frame WITH detections of a video is its own reference, whatever its number.
+One object serves ONE video: call `reset()` between videos (the reference re-seeds per video through frame_id == 1).
 `OmniMOTSFrame.run` = :770-892 (the MOTS twin): postprocess_inst + CondInst masks, `> mask_thres` at the original resolution,
 match(return_index=True), masks reordered to ascending track id, overlap-free merge (:860-865), pycocotools RLE strings (:889-892).
 
@@ -35,11 +38,29 @@ from ..utils.masks import mots_threshold
 from ..utils.timing import NoTimer
 
 
-def _to_pinned(t):
-    """async device -> pinned host copy on the current stream (the caller records / waits an event)"""
-    h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-    h.copy_(t, non_blocking=True)
-    return h
+class _PinnedPool:
+    """read-back buffers of the per-frame loops: pinned (rows, cols) fp32 buffers are taken from / returned to a small free list
+    instead of one `pin_memory()` allocation per frame and tensor (capacity = rows rounded up to a power of two, >= 64)"""
+
+    def __init__(self, keep=16):
+        self.free, self.keep = {}, keep
+
+    def to_pinned(self, t):
+        """async device -> pinned host copy on the current stream (the caller records / waits an event) -> (view, base)"""
+        n, cols = int(t.shape[0]), int(t.shape[1])
+        cap = 64
+        while cap < n:
+            cap *= 2
+        lst = self.free.setdefault((cap, cols, t.dtype), [])
+        base = lst.pop() if lst else torch.empty((cap, cols), dtype=t.dtype).pin_memory()
+        view = base[:n]
+        view.copy_(t, non_blocking=True)
+        return view, base
+
+    def release(self, base):
+        lst = self.free.setdefault((int(base.shape[0]), int(base.shape[1]), base.dtype), [])
+        if len(lst) < self.keep:
+            lst.append(base)
 
 
 class OmniMOTFrame:
@@ -50,7 +71,18 @@ class OmniMOTFrame:
         self.embed_score_thr = embed_score_thr                                              # mot_evaluator.py:1010
         self.pre_dict = None         # seq_dict of the last frame that had detections (:1020)
         self.frame_id = 0
+        self._streaming = False      # a run_stream generator of this object is alive (frames in flight on the launch stream)
+        self._pin = _PinnedPool()
         self.t = timer or NoTimer()
+
+    def reset(self, tracker=None):
+        """start a new video: forget the reference frame and the frame counter (mot_evaluator.py:1014 re-seeds at frame_id == 1);
+        `tracker` optionally replaces the association state (the reference builds a new tracker per video, :968-975)"""
+        if self._streaming:
+            raise RuntimeError("reset() while a run_stream pipeline of this object is in flight: exhaust or close the generator first")
+        self.pre_dict, self.frame_id = None, 0
+        if tracker is not None:
+            self.tracker = tracker
 
     # ---- stage A: network + postprocess launch over a batch of consecutive frames (no host sync)
     def _stage_a(self, imgs, info_img):
@@ -99,7 +131,7 @@ class OmniMOTFrame:
             # instance embeddings for EVERY detection (rows are independent); the score filter of :1009-1011 is applied on the host
             # copy, so no data-dependent shape is needed on the device
             feats = sample_embeddings(embed[b:b + 1], bboxes.contiguous())                  # :1024-1034 (uni_sample_embeddings)
-            tk.rows.append((_to_pinned(torch.cat((bboxes / scale, scores), dim=1)), _to_pinned(feats)))   # :1039-1042
+            tk.rows.append(self._pin.to_pinned(torch.cat((bboxes / scale, scores), dim=1)) + self._pin.to_pinned(feats))   # :1039-1042
         self.t.mark("embeddings")
         tk.ev_b = torch.cuda.Event()
         tk.ev_b.record()
@@ -120,7 +152,10 @@ class OmniMOTFrame:
             if rows is None:
                 tk.res.append((None, None))
                 continue
-            _, (out_b, _, out_ids) = self._match_frame(*rows)
+            ti, ti_base, tf, tf_base = rows
+            _, (out_b, _, out_ids) = self._match_frame(ti, tf)
+            self._pin.release(ti_base)               # match() copied what it keeps (numpy copies inside the native call wrapper)
+            self._pin.release(tf_base)
             valid = out_ids > -1                                                            # :1047-1051
             out_b, out_ids = out_b[valid], out_ids[valid]
             _, inds = out_ids.sort(descending=False)                                        # :1052-1055
@@ -144,6 +179,8 @@ class OmniMOTFrame:
     def run_stream(self, frames, info_img):
         """frames: iterable of (B,3,H,W) batches (B = 1: one frame per call) of ONE video in order -> yields run_batch's result per
         item, software-pipelined over the launch stream (module docstring)."""
+        if self._streaming:
+            raise RuntimeError("run_stream: another pipeline of this object is still in flight")
         it = iter(frames)
         pend = deque()
 
@@ -151,22 +188,26 @@ class OmniMOTFrame:
             img = next(it, None)
             if img is not None:
                 pend.append(self._stage_a(img, info_img))
-        admit()
-        admit()
-        cur = None
-        if pend:
-            cur = pend.popleft()
-            self._stage_b(cur)
-        admit()
-        while cur is not None:
-            self._host_assoc(cur)                    # waits for B(cur) only; the GPU keeps working on the admitted frames
-            nxt = None
-            if pend:
-                nxt = pend.popleft()
-                self._stage_b(nxt)
+        self._streaming = True
+        try:
             admit()
-            yield self._finish(cur)
-            cur = nxt
+            admit()
+            cur = None
+            if pend:
+                cur = pend.popleft()
+                self._stage_b(cur)
+            admit()
+            while cur is not None:
+                self._host_assoc(cur)                    # waits for B(cur) only; the GPU keeps working on the admitted frames
+                nxt = None
+                if pend:
+                    nxt = pend.popleft()
+                    self._stage_b(nxt)
+                admit()
+                yield self._finish(cur)
+                cur = nxt
+        finally:
+            self._streaming = False
 
 
 class OmniMOTSFrame(OmniMOTFrame):
@@ -203,7 +244,7 @@ class OmniMOTSFrame(OmniMOTFrame):
                 continue
             bboxes, scores = det[:, :4], det[:, 4:5] * det[:, 5:6]
             feats = sample_embeddings(embed[b:b + 1], bboxes.contiguous())
-            tk.rows.append((_to_pinned(torch.cat((bboxes / scale, scores), dim=1)), _to_pinned(feats)))
+            tk.rows.append(self._pin.to_pinned(torch.cat((bboxes / scale, scores), dim=1)) + self._pin.to_pinned(feats))
         self.t.mark("masks+embeddings")
         tk.ev_b = torch.cuda.Event()
         tk.ev_b.record()
@@ -217,11 +258,13 @@ class OmniMOTSFrame(OmniMOTFrame):
             if rows is None:
                 tk.pending.append(None)
                 continue
-            ti, tf = rows
+            ti, ti_base, tf, tf_base = rows
             keep = ti[:, 4] > self.embed_score_thr
             kept = torch.nonzero(keep)[:, 0]
             labels = torch.ones((int(kept.shape[0]),))
             out_b, _, out_ids, indexs = self.tracker.match(ti[keep], labels, tf[keep], self.frame_id, return_index=True)    # :843
+            self._pin.release(ti_base)               # ti[keep] / tf[keep] are copies
+            self._pin.release(tf_base)
             out_ids = torch.as_tensor(out_ids)
             valid = out_ids > -1
             idx = torch.nonzero(torch.as_tensor(indexs))[:, 0][valid]                       # masks[indexs][valid_inds] (:850-852)

@@ -90,8 +90,9 @@ class UnicornSOTTrack:
         posts, rows = [], []
         for b in range(len(prepped)):
             post = postprocess_launch(outputs[b], self.num_classes, self.confthre, self.nmsthre)
-            rw = torch.empty((self.max_inst, 7), dtype=torch.float32).pin_memory()
-            rw.copy_(post.det[:self.max_inst], non_blocking=True)      # rows past the survivor count are never read
+            n = min(self.max_inst, int(post.det.shape[0]))             # tiny inputs: fewer anchors than max_inst
+            rw = self._pinned_rows()
+            rw[:n].copy_(post.det[:n], non_blocking=True)              # rows past the survivor count are never read
             posts.append(post)
             rows.append(rw)
         ev = torch.cuda.Event()
@@ -99,13 +100,21 @@ class UnicornSOTTrack:
         self.t.mark("postprocess")
         return [(posts[b], rows[b], ev, prepped[b][1]) for b in range(len(prepped))]
 
+    def _pinned_rows(self):
+        """a (max_inst, 7) pinned read-back buffer from the tracker's own small pool (no allocation per frame in the latency loop);
+        collect() hands it back once the rows are copied out"""
+        pool = self.__dict__.setdefault("_pin_pool", [])
+        return pool.pop() if pool else torch.empty((self.max_inst, 7), dtype=torch.float32).pin_memory()
+
     def collect(self, ticket):
         post, rows, ev, r = ticket
         self.frame_id += 1
         ev.synchronize()
         m = int(post.n_host[0])
+        output = rows[:min(m, self.max_inst, int(post.det.shape[0]))].numpy().copy() if m > 0 else None
+        if len(self.__dict__.setdefault("_pin_pool", [])) < 8:
+            self._pin_pool.append(rows)
         if m > 0:
-            output = rows[:min(m, self.max_inst)].numpy().copy()
             output[:, 0:4:2] = np.clip(output[:, 0:4:2], 0, self.input_size[1])      # unicorn_sot.py:64-65 (same fp32 values as the device clamp)
             output[:, 1:4:2] = np.clip(output[:, 1:4:2], 0, self.input_size[0])
             b = output[:, 0:4] / r
