@@ -1155,3 +1155,50 @@ def test_gemm_h2_splitk(L, case):
     assert (outs[1] - outs[0]).abs().max() < tol * scale
     if G:
         assert (stats[1][:2 * G] - stats[0][:2 * G]).abs().max() < 1e-5 * stats[0][:2 * G].abs().max()
+
+
+# ------------------------------------------------------------------------------------------------
+# independent sanity bounds for the UNPINNED third-party restatements: the device kernels against
+# tests/sanity_refs.py -- second statements written by a different route than oracle/*.py (CPU half: tests/test_sanity_bounds_cpu.py)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,size,swap", [((1080, 1920), (800, 1280), True), ((480, 640), (800, 1280), True),
+                                             ((375, 1242), (800, 1280), False)])
+def test_letterbox_device_within_one_lsb_of_float_bilinear(L, shape, size, swap):
+    """uni_letterbox (OpenCV's 11-bit fixed point) vs torch's FLOAT bilinear on the same uint8 image: never more than one LSB apart,
+    >= 90 % identical after rounding, pad value exact; a smooth ramp exposes coordinate / orientation errors."""
+    import sanity_refs as sr
+    from unicorn_amd.ops import letterbox
+    g = np.random.default_rng(shape[0] + shape[1])
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    ramp = np.stack([(xx * 255.0 / shape[1]), (yy * 255.0 / shape[0]), ((xx + yy) * 255.0 / (shape[0] + shape[1]))], -1).astype(np.uint8)
+    for img in (g.integers(0, 256, shape + (3,), dtype=np.uint8), ramp):
+        out, r = letterbox(img, size, swap_rb=swap)
+        ref, r2, (rh, rw) = sr.float_letterbox(img, size, swap)
+        o = out[0].cpu().numpy().astype(np.float64)
+        assert r == r2 and np.abs(o - ref).max() <= 1.0
+        assert (o == np.rint(ref)).mean() > 0.9
+        assert (o[:, rh:] == 114).all() and (o[:, :, rw:] == 114).all()
+
+
+def test_nms_device_vs_brute_force_adversarial(L):
+    """uni_nms against scalar O(N^2) greedy loops written from the torchvision docstring: IoU exactly at the threshold (strict >),
+    equal scores (lower index first), class offsets of the coordinate trick near the fp32 resolution, a dense field"""
+    import sanity_refs as sr
+    from unicorn_amd.utils.boxes import batched_nms, nms
+    for name, b, s, c, thr in sr.adversarial_nms_cases():
+        tb, ts, tc = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(np.asarray(c, np.int64)).cuda()
+        assert nms(tb, ts, thr).cpu().tolist() == sr.brute_nms(b, s, thr), name
+        assert batched_nms(tb, ts, tc, thr).cpu().tolist() == sr.brute_batched_nms(b, s, c, thr), name
+
+
+def test_rle_device_strings_decode_through_the_independent_reader(L):
+    """uni_rle_encode strings of 1-pixel, all-ones, column- / row-alternating and empty masks through a character-level reader of the
+    documented pycocotools format (not the oracle's codec)"""
+    import sanity_refs as sr
+    from unicorn_amd.ops import rle_encode
+    cases = sr.rle_sanity_masks()
+    for shape in sorted({m.shape for _, m in cases}):
+        group = [(n, m) for n, m in cases if m.shape == shape]
+        strs = rle_encode(torch.from_numpy(np.stack([m for _, m in group])).cuda())
+        for (n, m), s in zip(group, strs):
+            assert np.array_equal(sr.coco_rle_string_to_mask(s, *shape), m), (n, shape, s)
