@@ -94,3 +94,27 @@ def test_timed_loop_keeps_calling_collectives_after_a_rank_error():
     assert len(calls) == 4 and len(errs) == 1 and "boom" in errs[0] and S.n == 4      # steps 0..3 ran, 4..7 skipped, all 4 gathers called
     with pytest.raises(RuntimeError):
         bench.timed([S()], steps=6, warmup=2, barrier=lambda: None)
+
+
+def test_gpu_sensor_summary_uses_only_the_timed_window():
+    """clock / power statistics come from the samples BETWEEN the two barriers of the timed steps (median, p10, p90,
+    fraction of samples within 3 % of the power cap), not from a mean over warm-up + ramp; timed() hands the window out."""
+    sys.path.insert(0, ROOT)
+    import bench
+    s = bench.GpuSensor.__new__(bench.GpuSensor)
+    s.paths, s.period = ("/nonexistent", "/nonexistent", "/nonexistent"), 0.005
+    # warm-up / ramp: low clock, low power (t < 10); timed window: 2000 MHz at 1380 W of a 1400 W cap, one dip
+    s.samples = [(900.0, 300.0, float(t)) for t in range(10)] + [(2000.0, 1380.0, 10.0 + t) for t in range(19)] + [(1500.0, 1000.0, 29.0)]
+    whole, win = s.summary(), s.summary(window=(10.0, 29.0))
+    assert whole["samples"] == 30 and win["samples"] == 20
+    assert win["sclk_mhz_median"] == 2000.0 and win["sclk_mhz_p10"] == 2000.0 and win["sclk_mhz_min"] == 1500.0
+    assert win["power_w_median"] == 1380.0 and win["power_cap_w"] is None and win["frac_samples_within_3pct_of_power_cap"] is None
+    assert whole["sclk_mhz_mean"] < 1700 < win["sclk_mhz_mean"]
+    assert s.summary(window=(100.0, 200.0)) is None
+
+    class _S:
+        def step(self, i):
+            pass
+    w = []
+    dt, own, _ = bench.timed([_S()], 3, 1, lambda: None, window=w)
+    assert len(w) == 2 and abs((w[1] - w[0]) - dt) < 1e-6
