@@ -896,7 +896,10 @@ def main():
                                                           "2 x upsample -> correlation -> head -> uni_postprocess (conf thr set for ~200 candidates) -> box")
             # (b) evaluate_omni loop, one frame per call
             ms_.omni.t = StageTimer()
-            ms_.omni.pre_dict, ms_.omni.frame_id = None, 0
+            if ms_._gen is not None:               # the timed loop's pipelined generator still has frames admitted: retire it first
+                ms_._gen.close()
+                ms_._gen = None
+            ms_.omni.reset()                       # a new "video" (tracker/omni.py: refuses while a pipeline is in flight)
             configs["mot_omni_loop"] = staged(lambda i: ms_.omni.run(ms_.frames[1 + i % 4], (1080, 1920)), ms_.omni.t,
                                               stream=lambda k: sum(1 for _ in ms_.omni.run_stream((ms_.frames[1 + j % 4] for j in range(k)), (1080, 1920))),
                                               set_timer=lambda t_: setattr(ms_.omni, "t", t_))

@@ -26,6 +26,7 @@
  *                            condinst/mask_branch.py:77-99,158-162)
  *   uni_condinst_masks      DynamicMaskHead.__call__ + aligned_bilinear(d_rate)
  *                           (condinst/dynamic_mask_head.py:172-225; utils/boxes.py:138-146)
+ *   uni_condinst_masks_u8   the same fused with the 1/r resize + `> mask_thres` of the MOTS loop (mot_evaluator.py:804-805)
  *   uni_letterbox           PreprocessorX.process / preproc (unicorn_sot.py:111-123, data/data_augment.py:194-214)
  *   uni_postprocess         postprocess + torchvision nms/batched_nms (utils/boxes.py:33-77)
  *   uni_prior_pyramid       F.interpolate(coarse, 1/2 | 1/4, bilinear) (unicorn_sot.py:103-105)
@@ -188,6 +189,15 @@ int uni_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre
  * out_bin = prob > thr as bytes (unicorn/evaluators/mot_evaluator.py:804-805).  Either output may be NULL. */
 int uni_mask_resize(const float* masks, int N, int Hn, int Wn, double r, int H, int W, float thr, float* out_prob,
                     uint8_t* out_bin, uni_stream_t stream);
+/* postprocess_inst's mask half + the MOTS threshold in ONE call, for callers that never look at the network-size maps
+ * (unicorn/utils/boxes.py:138-146 -> unicorn/models/condinst/dynamic_mask_head.py:159-225 -> unicorn/evaluators/mot_evaluator.py:804-805;
+ * the VOS paste of external/lib/test/tracker/unicorn_vos.py:141-152 with out_prob): arguments of uni_condinst_masks, then
+ * F.interpolate(scale_factor=1/r, bilinear)[:, :H, :W] pasted into zero (n,H,W) maps as fp32 (out_prob) and / or `> thr` bytes (out_bin);
+ * either may be NULL.  The (n, d_rate*r*H8, d_rate*r*W8) fp32 maps are never written; results are bit-identical to
+ * uni_condinst_masks followed by uni_mask_resize.  workspace >= n*H8*W8*(1+r*r)*4 bytes. */
+int uni_condinst_masks_u8(const float* mask_feats, const float* up_masks, const float* params, int ldp, const float* inst_loc,
+                          const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate, double r, int H, int W, float thr,
+                          float* out_prob, uint8_t* out_bin, void* workspace, size_t workspace_bytes, uni_stream_t stream);
 /* Soft aggregation of unicorn_vos.py:99-120 fused with that resize: probs (K1,Hn,Wn) of the tracked objects (ids prob_ids, in
  * cur_obj_ids order), init_masks (K2,H,W) {0,1} of objects introduced in this frame (ids init_ids); background =
  * prod(1 - p), argmax over [background, ids] (numpy first-maximum rule) -> out (H,W) uint8 id map. */

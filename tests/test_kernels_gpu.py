@@ -547,6 +547,34 @@ def test_condinst_masks(L):
     assert condinst_masks(mf.cuda(), um.cuda(), params[:0].cuda(), loc[:0].cuda(), lvl[:0], 4, 2).shape == (0, 1, 160, 224)
 
 
+@pytest.mark.parametrize("H8,W8,r,H,W", [(40, 64, 0.6667, 480, 768),        # the 1080p geometry (r = 800 / 1200) at a small size
+                                         (40, 64, 1.0, 320, 512),            # identity resize
+                                         (25, 40, 0.8333333, 250, 390),      # ragged: output tile and window edges, H / W not multiples of the tile
+                                         (40, 64, 1.4988, 214, 342),         # image smaller than the network input; output one pixel short of img (853-style)
+                                         (40, 64, 2.7, 118, 189),            # strong down-scaling: the tile's window exceeds the LDS -> sample-per-tap path
+                                         (100, 160, 0.66666667, 1080, 1920)])  # the bench geometry
+def test_condinst_resized_fused_equals_two_pass(L, H8, W8, r, H, W):
+    """uni_condinst_masks_u8 (CondInst convex upsample -> aligned bilinear x d_rate -> 1/r bilinear -> `> thr`, chained through LDS) must be
+    BIT-IDENTICAL to uni_condinst_masks followed by uni_mask_resize (the (n, Hn, Wn) fp32 maps in HBM): bytes and fp32 probabilities."""
+    from unicorn_amd.ops import condinst_masks, condinst_masks_resized, mask_resize
+    g = torch.Generator().manual_seed(H8 * 7 + W)
+    n = 7
+    mf = torch.randn(1, 8, H8, W8, generator=g).cuda()
+    um = torch.randn(1, 144, H8, W8, generator=g).cuda()
+    params = (torch.randn(n, 169, generator=g) * 0.5).cuda()
+    loc = (torch.rand(n, 2, generator=g) * torch.tensor([W8 * 8.0, H8 * 8.0])).cuda()
+    lvl = torch.tensor([0, 1, 2, 0, 1, 3, 4])
+    for d_rate in (2, 1):
+        full = condinst_masks(mf, um, params, loc, lvl, 4, d_rate)[:, 0]
+        for thr in (0.3, 0.5, None):
+            ref = mask_resize(full, r, H, W, thr=thr)
+            got = condinst_masks_resized(mf, um, params, loc, lvl, 4, d_rate, r, H, W, thr=thr)
+            assert got.dtype == ref.dtype and got.shape == ref.shape
+            assert torch.equal(got, ref), (d_rate, thr, int((got != ref).sum()))
+        assert 0.02 < float(mask_resize(full, r, H, W, thr=0.5).float().mean()) < 0.98          # the threshold actually cuts through the maps
+    assert condinst_masks_resized(mf, um, params[:0], loc[:0], lvl[:0], 4, 2, r, H, W, thr=0.3).shape == (0, H, W)
+
+
 from planted import planted_pred as _planted_pred  # noqa: E402
 
 

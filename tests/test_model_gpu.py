@@ -745,6 +745,16 @@ def test_omni_stream_pipelined_equals_per_frame():
     same = sum(int(a == b) for x, y in zip(r1, rp) for a, b in zip(x[1], y[1]))
     assert same >= 0.9 * sum(len(r[1]) for r in r1), same       # RLE strings: identical unless a probability sits within round-off of the threshold
     assert sum(len(r[1]) for r in r1) > 20 and all(isinstance(s_, str) for r in r1 for s_ in r[1])
+    # the fused CondInst -> resized bytes entry point (uni_condinst_masks_u8, the default) against the two-pass path through the network-size
+    # fp32 masks of the reference API: identical masks for the same detections (bit-identical kernels, tests/test_kernels_gpu.py)
+    two = mks()
+    two.fused_masks = False
+    assert one.fused_masks
+    with torch.no_grad():
+        r2 = [two.run(f, info) for f in fr]
+    assert [r[0] for r in r1] == [r[0] for r in r2]
+    same2 = sum(int(a == b) for x, y in zip(r1, r2) for a, b in zip(x[1], y[1]))
+    assert same2 >= 0.9 * sum(len(r[1]) for r in r1), same2      # (the network outputs themselves carry fp64-atomic order noise between runs)
     del mm
     # ---- SOT
     ms, _, _ = build("unicorn_track_tiny", "f16x2")

@@ -101,12 +101,13 @@ __global__ __launch_bounds__(256, 1) void gemm_feed_kernel(const char* __restric
     for (int i = 0; i < A_PC; ++i) voa[i] = (8 * (wave + 4 * i) + (lane >> 3)) * sa + (lane & 7) * 16;
 #pragma unroll
     for (int i = 0; i < B_PC; ++i) vob[i] = (8 * (wave + 4 * i) + (lane >> 3)) * sw + (lane & 7) * 16;
-    auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
+    auto issue = [&](int kt, int slot) __attribute__((always_inline)) {       // kt < 0: a dead request (per-lane offset out of range: zeros; the scalar offset is NOT range-checked)
         char* dst = smem + slot * (BM + BN) * 128 + wave * 1024;
+        const bool live = kt >= 0;
 #pragma unroll
-        for (int i = 0; i < A_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, voa[i], kt * 128, 0, 0);
+        for (int i = 0; i < A_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, live ? voa[i] : 0x7fffffff, live ? kt * 128 : 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < B_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + BM * 128 + i * 4096), 16, vob[i], kt * 128, 0, 0);
+        for (int i = 0; i < B_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + BM * 128 + i * 4096), 16, live ? vob[i] : 0x7fffffff, live ? kt * 128 : 0, 0, 0);
     };
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) issue(d, d % SLOTS);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void gemm_feed_kernel(const char* __restric
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 2) * PER) : "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
-        issue(kt + DEPTH - 1 < nk ? kt + DEPTH - 1 : 0x7fffff, wr);     // past the end: out of range, zeros (as the kernel does)
+        issue(kt + DEPTH - 1 < nk ? kt + DEPTH - 1 : -1, wr);     // past the end: dead requests (as the kernel does)
         wr = wr + 1 == SLOTS ? 0 : wr + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,6 +148,148 @@ static void run_gemm(const char* buf, unsigned* sink, int M, int N, int K, int p
            BARRIER ? " +barrier" : "         ", pad_a, pad_w, best * 1e3, bytes / best / 1e9, bytes / best / 1e6 / (grid < 256 ? grid : 256) / 2.1);
 }
 
+// ---- the same request stream WITH the MFMA / fragment-read load of the 128 x 96 deep tile (TM = 1, TN = 3: 18 MFMAs + 16 ds_read_b128 per
+// wave and K step), two ways:  SPEC = false: every wave issues its DMA requests between its own MFMAs (gemm_h2d_kernel's schedule, 4 waves);
+// SPEC = true: 8 waves, waves 0-3 only read fragments and multiply, waves 4-7 only issue the DMA requests (one producer + one consumer per
+// SIMD) -- does a second wave per SIMD take the VMEM issue stalls off the MFMA stream?
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <bool SPEC, int DEPTH>
+__global__ __launch_bounds__(SPEC ? 512 : 256, 1) void gemm_mix_kernel(const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ sink, int M, int N,
+                                                                       int nk, int sa, int sw) {
+    constexpr int BM = 128, BN = 96, A_PC = 4, B_PC = 3, PER = 7;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = !SPEC || wave >= 4, consumer = !SPEC || wave < 4;
+    const int pw = wave & 3;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + BM - 1) / BM, nwg = gridDim.x;
+    int L;
+    { const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7; L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3); }
+    const int per_chunk = nbm * 8, c = L / per_chunk, wc = min(8, nbn - c * 8), rem = L - c * per_chunk;
+    const int bm = rem / wc, bn = c * 8 + rem - bm * wc;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A) + (size_t)bm * BM * sa, 0, min(BM, M - bm * BM) * sa, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(W) + (size_t)bn * BN * sw, 0, min(BN, N - bn * BN) * sw, 0x00020000);
+    int voa[8], vob[8];
+#pragma unroll
+    for (int i = 0; i < A_PC; ++i) voa[i] = (8 * (pw + 4 * i) + (lane >> 3)) * sa + (lane & 7) * 16;
+#pragma unroll
+    for (int i = 0; i < B_PC; ++i) vob[i] = (8 * (pw + 4 * i) + (lane >> 3)) * sw + (lane & 7) * 16;
+    auto issue = [&](int kt, int slot, bool live) __attribute__((always_inline)) {
+        char* dst = smem + slot * (BM + BN) * 128 + pw * 1024;
+#pragma unroll
+        for (int i = 0; i < A_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, live ? voa[i] : 0x7fffffff, kt * 128, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + BM * 128 + i * 4096), 16, live ? vob[i] : 0x7fffffff, kt * 128, 0, 0);
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    f16x8 fa[2][2], fb[2][6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { fa[1][i] = f16x8{}; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { fb[1][i] = f16x8{}; }
+    auto ldfrag = [&](int sbase, int half, int set) __attribute__((always_inline)) {
+        const int row = pw * 32 + (lane & 31), ch = 2 * (2 * half + (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((size_t)(sbase + row * 128 + (((ch + i) ^ ((row >> 1) & 7)) << 4)));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rb = BM + j * 32 + (lane & 31);
+                fb[set][2 * j + i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((size_t)(sbase + rb * 128 + (((ch + i) ^ ((rb >> 1) & 7)) << 4)));
+            }
+    };
+    auto mma = [&](int set, int term) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? fb[set][2 * j + 1] : fb[set][2 * j], term == 1 ? fa[set][1] : fa[set][0], acc[j], 0, 0, 0);
+    };
+    if (producer)
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) issue(d, d, d < nk);
+    int rd = 0, wr = DEPTH - 1;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (producer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 2) * PER) : "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int sbase = lds0 + rd * (BM + BN) * 128;
+        rd = rd + 1 == DEPTH ? 0 : rd + 1;
+        if (SPEC) {
+            if (consumer) {
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldfrag(sbase, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 1); mma(1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldfrag(sbase, 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 1); mma(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                issue(kt + DEPTH - 1, wr, kt + DEPTH - 1 < nk);
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(sbase, 0, 0);
+            issue(kt + DEPTH - 1, wr, kt + DEPTH - 1 < nk);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 1); mma(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(sbase, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 1); mma(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wr = wr + 1 == DEPTH ? 0 : wr + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[j][r];
+    if (t == 1234.5f) sink[0] = t;
+}
+
+template <bool SPEC, int DEPTH>
+static void run_mix(const char* buf, float* sink, int M, int N, int K) {
+    const int sa = K * 4, sw = K * 4, nk = K / 32;
+    const char* A = buf;
+    const char* W = buf + (((size_t)M * sa + 4095) & ~(size_t)4095);
+    const int grid = ((M + 127) / 128) * ((N + 95) / 96);
+    const size_t lds = (size_t)DEPTH * (128 + 96) * 128;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mix_kernel<SPEC, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((gemm_mix_kernel<SPEC, DEPTH>), dim3(grid), dim3(SPEC ? 512 : 256), lds, 0, A, W, sink, M, N, nk, sa, sw);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("gemm feed + MFMA %5d x %4d x %4d  tile 128 x 96 (%3d blocks)  %d deep  %s: %7.1f us  (%.0f TF-eq of f16x2 products)\n", M, N, K, grid, DEPTH,
+           SPEC ? "8 waves: 4 consumers + 4 producers" : "4 waves, DMA issued between the MFMAs  ", best * 1e3, 2.0 * M * N * K / best / 1e9);
+}
+
 int main(int argc, char** argv) {
     const unsigned win = (argc > 1 ? atoi(argv[1]) : 2) << 20;
     const int nblk = argc > 2 ? atoi(argv[2]) : 256;
@@ -173,6 +316,12 @@ int main(int argc, char** argv) {
         char* big;
         hipMalloc(&big, (size_t)512 << 20);
         hipMemset(big, 1, (size_t)512 << 20);
+        run_mix<false, 4>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<true, 4>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<false, 3>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<true, 5>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<false, 4>(big, (float*)sink, 4000, 768, 1536);
+        run_mix<true, 4>(big, (float*)sink, 4000, 768, 1536);
         const int pads[][2] = {{0, 0}, {128, 128}, {256, 256}, {128, 0}, {0, 128}, {512, 512}};
         for (auto& pd : pads) {
             run_gemm<128, 96, 4, true>(big, sink, 4000, 768, 3072, pd[0], pd[1]);      // stage-2 pwconv2 of one frame

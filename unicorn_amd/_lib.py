@@ -51,6 +51,8 @@ PROTOS = {
     "uni_postprocess": (c_i, [c_f, c_i, c_i, c_i, C.c_float, C.c_float, c_i, c_i, c_f, c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uni_sample_embeddings": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, C.c_float, c_f, C.c_void_p]),
     "uni_condinst_masks": (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uni_condinst_masks_u8": (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_double, c_i, c_i, C.c_float, c_f, c_f, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "uni_mask_resize": (c_i, [c_f, c_i, c_i, c_i, C.c_double, c_i, c_i, C.c_float, c_f, c_f, C.c_void_p]),
     "uni_vos_merge": (c_i, [c_f, c_f, c_i, c_i, c_i, C.c_double, c_f, c_f, c_i, c_i, c_i, c_f, C.c_void_p]),
     "uni_mots_overlap_free": (c_i, [c_f, c_i, c_i, c_i, c_f, C.c_void_p]),

@@ -199,6 +199,25 @@ int uni_mask_resize(const float* masks, int N, int Hn, int Wn, double r, int H, 
     resize_geometry(Hn, Wn, r, &ho, &wo, &rs);
     API(launch_mask_resize(masks, N, Hn, Wn, rs, ho, wo, H, W, thr, out_prob, out_bin, S(stream)));
 }
+int uni_condinst_masks_u8(const float* mask_feats, const float* up_masks, const float* params, int ldp, const float* inst_loc,
+                          const int32_t* inst_lvl, int n, int H8, int W8, int up_rate, int d_rate, double r, int H, int W, float thr,
+                          float* out_prob, uint8_t* out_bin, void* workspace, size_t workspace_bytes, uni_stream_t stream) {
+    if (n == 0) return 0;
+    UNI_REQUIRE(mask_feats && up_masks && params && inst_loc && inst_lvl && (out_prob || out_bin) && workspace && r > 0, "condinst_u8: bad argument");
+    const size_t need = (size_t)n * H8 * W8 * (1 + up_rate * up_rate) * sizeof(float);
+    UNI_REQUIRE(workspace_bytes >= need, "condinst_u8: workspace %zu < %zu", workspace_bytes, need);
+    CondInstArgs a;
+    a.mask_feats = mask_feats; a.up_masks = up_masks; a.params = params; a.ldp = ldp; a.inst_loc = inst_loc; a.inst_lvl = inst_lvl;
+    a.n = n; a.H = H8; a.W = W8; a.r = up_rate; a.d_rate = d_rate;
+    a.logits_ws = reinterpret_cast<float*>(workspace);
+    a.coarse_ws = a.logits_ws + (size_t)n * H8 * W8;
+    a.out = nullptr;                                   // stop after the convex upsample: coarse_ws holds (n, r H8, r W8) sigmoid scores
+    int rc = launch_condinst(a, S(stream));
+    if (rc) return rc;
+    int ho, wo; float rs;
+    resize_geometry(d_rate * up_rate * H8, d_rate * up_rate * W8, r, &ho, &wo, &rs);
+    API(launch_condinst_resize(a.coarse_ws, n, up_rate * H8, up_rate * W8, d_rate, rs, ho, wo, H, W, thr, out_prob, out_bin, S(stream)));
+}
 int uni_vos_merge(const float* probs, const int32_t* prob_ids, int K1, int Hn, int Wn, double r, const uint8_t* init_masks,
                   const int32_t* init_ids, int K2, int H, int W, uint8_t* out, uni_stream_t stream) {
     UNI_REQUIRE(out && (K1 == 0 || (probs && prob_ids)) && (K2 == 0 || (init_masks && init_ids)) && r > 0, "vos_merge: bad argument");

@@ -7,7 +7,7 @@ mkdir -p $OUT build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
 pids=()
 for f in gemm gemm_h2 gemm_h2d gemm_h2q gemm_p44 mlp_fused norm msda corr misc post mask_post engine api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ gemm_epi.h -nt build/$f.o ] || [ ../../include/unicorn_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ gemm_epi.h -nt build/$f.o ] || [ mask_interp.h -nt build/$f.o ] || [ ../../include/unicorn_hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

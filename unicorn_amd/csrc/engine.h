@@ -53,7 +53,7 @@ struct uni_ctx {
     int nb = 1;   // batch size of the stage call in flight
     bool prof_on = false; std::vector<ProfRec> recs; double prof_bytes = 0.0;
     bool check_sat = false; unsigned long long* sat_dev = nullptr;   // uni_ctx_set_check: [saturated f16x2 operands, operands scanned, buffers scanned]
-    hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr; hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr};   // head: levels 16 / 32 and the mask branch run beside level 8
 };
 
 uint16_t f32_to_bf16_host(float f);

@@ -315,7 +315,7 @@ int engine_finalize(uni_ctx* c) {
     // GroupNorm statistics arena (zeroed at the start of every stage call)
     UNI_CHECK_HIP(hipMalloc(&c->stats, UNI_STATS_SLOTS * 64 * sizeof(double)));
     c->dev_allocs.push_back(c->stats);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         UNI_CHECK_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         UNI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
@@ -829,7 +829,10 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     // The three FPN levels are independent until the decode: run them concurrently (the stride-16/32 levels are
     // far too small to fill 256 CUs on their own).  Level k gets its own stream and a disjoint workspace slice.
     static const bool no_fork = getenv("UNI_NO_FORK") != nullptr;     // A/B switch
-    const bool fork = c->aux[0] && c->aux[1] && !c->prof_on && !no_fork;   // serialised while event-profiling so per-kernel times are not inflated by overlap
+    const bool fork = c->aux[0] && c->aux[1] && c->aux[2] && !c->prof_on && !no_fork;   // serialised while event-profiling so per-kernel times are not inflated by overlap
+    static const bool no_fork_mb = getenv("UNI_NO_FORK_MB") != nullptr;                 // A/B switch: mask branch after the levels, on the caller's stream
+    const bool fork_mb = fork && cfg.mask && !no_fork_mb;
+    const int njoin = fork_mb ? 3 : 2;
     hipStream_t s_main = s;
     // an error inside the forked region must not leave the auxiliary streams unjoined (the caller's stream would otherwise race the
     // levels still in flight): RUN joins them before it returns
@@ -839,7 +842,7 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
         int _rc = (expr);                                                                      \
         if (_rc || c->ws_overflow) {                                                           \
             if (fork)                                                                          \
-                for (int _i = 0; _i < 2; ++_i)                                                 \
+                for (int _i = 0; _i < njoin; ++_i)                                             \
                     if (hipEventRecord(c->ev_join[_i], c->aux[_i]) == hipSuccess) (void)hipStreamWaitEvent(s_main, c->ev_join[_i], 0); \
             return _rc ? _rc : -3;                                                             \
         }                                                                                      \
@@ -851,12 +854,47 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     };
     if (fork) {
         RUN(hip_rc(hipEventRecord(c->ev_fork, s_main), "hipEventRecord(fork)"));
-        for (int i = 0; i < 2; ++i) RUN(hip_rc(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0), "hipStreamWaitEvent(fork)"));
+        for (int i = 0; i < njoin; ++i) RUN(hip_rc(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0), "hipStreamWaitEvent(fork)"));
     }
+    // condinst/mask_branch.py:77-99,158-162: depends on the FPN maps only -> once per IMAGE, and (forked) on its own stream BESIDE the three
+    // levels: its GEMMs are 16000-row x 128-column problems (125 tiles of 128 x 128 at one frame) that leave half of the chip idle when they
+    // run alone after the join (mask head 2.10 vs 1.49 ms for the plain head at one frame)
+    auto mask_branch = [&](hipStream_t s) -> int {
+        c->nb = Bi;
+        const int M8 = Bi * HWk[0];
+        float* xm = wsalloc<float>(c, (size_t)M8 * 128);
+        for (int k = 0; k < 3; ++k) {
+            const int M = Bi * HWk[k];
+            float* r = k == 0 ? xm : wsalloc<float>(c, (size_t)M * 128);
+            Out o; o.F = r; o.ldf = 128;
+            RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
+            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s, Bi); }));
+        }
+        ActPtr xmb = actalloc(c, (size_t)M8 * 128);
+        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_operand(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
+        ActPtr tb[2] = {actalloc(c, (size_t)M8 * 128), actalloc(c, (size_t)M8 * 128)};
+        ActPtr cur = xmb;
+        for (int i = 0; i < 4; ++i) {
+            Out o; o.B = tb[i & 1]; o.ldb = 128;
+            RUN(run_conv_gn(c, c->mtower[i], c->mtower_gn[i], 16, 1e-3f, ACT_RELU, cur, 128, Hk[0], Wk[0], 1, o, s));
+            cur = tb[i & 1];
+        }
+        { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(p_gemm(c, g, s)); }
+        ActPtr u = tb[0] == cur ? tb[1] : tb[0];
+        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1, Bi); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
+        { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(p_gemm(c, g, s)); }
+        return 0;
+    };
     const size_t lvl_base = (c->ws_off + 255) & ~(size_t)255;
     const size_t M0 = (size_t)B * HWk[0];
     const size_t slice_bytes = ((M0 * 16384) + 65536 + UNI_SLAB_BYTES + 4096 + 255) & ~(size_t)255;   // >= per-level footprint at level 0 (bf16 9.2 KB/pixel, fp32 15.4 KB/pixel) + one split-K slab
     const int row_start[3] = {0, HWk[0], HWk[0] + HWk[1]};
+    size_t mb_end = 0;
+    if (fork_mb) {      // its workspace lies behind the three level slices (where the serial version allocates it, too)
+        c->ws_off = lvl_base + 3 * slice_bytes;
+        RUN(mask_branch(c->aux[2]));
+        mb_end = c->ws_off;
+    }
     for (int k = 0; k < 3; ++k) {
         const int M = B * HWk[k];                                // rows over the batch at this level
         const int row0 = row_start[k];
@@ -925,40 +963,16 @@ int engine_head(uni_ctx* c, const float* fpn0, const float* fpn1, const float* f
     }
     s = s_main;
     if (fork) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < njoin; ++i) {
             RUN(hip_rc(hipEventRecord(c->ev_join[i], c->aux[i]), "hipEventRecord(join)"));
             RUN(hip_rc(hipStreamWaitEvent(s_main, c->ev_join[i], 0), "hipStreamWaitEvent(join)"));
         }
-        c->ws_off = lvl_base + 3 * slice_bytes;
+        c->ws_off = fork_mb ? mb_end : lvl_base + 3 * slice_bytes;
     }
 #undef RUN
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; if (c->ws_overflow) return -3; } while (0)
     if (!raw) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_decode(out, out, HWk[0], Wk[0], HWk[1], Wk[1], HWk[2], Wk[2], nch, s, B); }));
-    if (cfg.mask) {   // condinst/mask_branch.py:77-99,158-162 (depends on the FPN maps only: once per IMAGE)
-        c->nb = Bi;
-        const int M8 = Bi * HWk[0];
-        float* xm = wsalloc<float>(c, (size_t)M8 * 128);
-        for (int k = 0; k < 3; ++k) {
-            const int M = Bi * HWk[k];
-            float* r = k == 0 ? xm : wsalloc<float>(c, (size_t)M * 128);
-            Out o; o.F = r; o.ldf = 128;
-            RUN(run_conv_gn(c, c->refine[k], c->refine_gn[k], 16, 1e-3f, ACT_RELU, fb[k], ch[k], Hk[k], Wk[k], 1, o, s));
-            if (k > 0) RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_add_aligned_bilinear(r, Hk[k], Wk[k], 128, Hk[0] / Hk[k], xm, s, Bi); }));
-        }
-        ActPtr xmb = actalloc(c, (size_t)M8 * 128);
-        RUN(prof_run(c, PC_MISC, 0.0, s, [&] { return launch_cast_operand(xm, 128, xmb, 128, M8, 128, s, c->b32); }));
-        ActPtr tb[2] = {actalloc(c, (size_t)M8 * 128), actalloc(c, (size_t)M8 * 128)};
-        ActPtr cur = xmb;
-        for (int i = 0; i < 4; ++i) {
-            Out o; o.B = tb[i & 1]; o.ldb = 128;
-            RUN(run_conv_gn(c, c->mtower[i], c->mtower_gn[i], 16, 1e-3f, ACT_RELU, cur, 128, Hk[0], Wk[0], 1, o, s));
-            cur = tb[i & 1];
-        }
-        { GemmArgs g = conv_args(c->mtower_out, cur, 128, M8, 1, 1, 0); g.outF = mask_feats; g.ldf = 8; RUN(p_gemm(c, g, s)); }
-        ActPtr u = tb[0] == cur ? tb[1] : tb[0];
-        { GemmArgs g = conv_args(c->upm0, xmb, 128, Hk[0], Wk[0], 1, 1, Bi); g.act = ACT_RELU; g.outB = u; g.ldb = 128; RUN(p_gemm(c, g, s)); }
-        { GemmArgs g = conv_args(c->upm1, u, 128, M8, 1, 1, 0); g.outF = up_masks; g.ldf = c->upm1.N; RUN(p_gemm(c, g, s)); }
-    }
+    if (cfg.mask && !fork_mb) RUN(mask_branch(s));
     return 0;
 }
 
@@ -968,7 +982,7 @@ void engine_destroy(uni_ctx* c) {
     (void)hipDeviceSynchronize();
     for (void* p : c->dev_allocs) (void)hipFree(p);
     if (c->ws) (void)hipFree(c->ws);
-    for (int i = 0; i < 2; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
+    for (int i = 0; i < 3; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }

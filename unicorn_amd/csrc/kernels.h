@@ -180,6 +180,10 @@ int launch_nms(const float* boxes, const float* scores, int n, float iou_thr, in
 int launch_postprocess(float* pred, int A, int ld, int num_classes, float conf_thre, float nms_thre, int flags,
                        int max_det, float* det_out, int32_t* keep_idx, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t s);
 // mask_post.hip: mask post-processing of the VOS / MOTS drivers (row N1)
+// coarse (N, h, w) CondInst sigmoid scores at 1 / d_rate of the network resolution -> aligned_bilinear(x f) -> resize by 1 / r -> fp32 and / or
+// `> thr` bytes at (H, W), without the (N, f h, f w) intermediate (bit-identical to launch_condinst's last pass + launch_mask_resize)
+int launch_condinst_resize(const float* coarse, int N, int h, int w, int f, float rscale, int ho, int wo, int H, int W, float thr, float* outF,
+                           unsigned char* outU, hipStream_t s);
 int launch_mask_resize(const float* masks, int N, int Hn, int Wn, float rscale, int ho, int wo, int H, int W, float thr, float* outF,
                        unsigned char* outU, hipStream_t s);
 int launch_vos_merge(const float* probs, const int* prob_ids, int K1, int Hn, int Wn, float rscale, int ho, int wo,

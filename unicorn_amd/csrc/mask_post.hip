@@ -8,34 +8,14 @@
 //   rle_*                  pycocotools rleEncode (column-major runs) + rleToString (mot_evaluator.py:889-892)
 // HBM-bound streaming kernels: coalesced along x, one pass over the inputs.
 #include "kernels.h"
+#include "mask_interp.h"
 
 // the float arithmetic below must round exactly like the numpy restatement: no fused multiply-add anywhere in this file
 #pragma clang fp contract(off)
 
 namespace {
-// ATen UpSample.h: area_pixel_compute_source_index (align_corners = false) + guard_index_and_lambda, fp32, plain operators under
-// `fp contract(off)` (the __fmul_rn-style wrappers are inlined from headers compiled WITH contraction and fuse anyway)
-// (the oracle repeats exactly this operation order in numpy)
-struct SrcIdx { int i0, i1; float w0, w1; };
-__device__ __forceinline__ SrcIdx src_index(int d, int n_in, float rscale) {
-    float real = rscale * ((float)d + 0.5f) - 0.5f;
-    real = fmaxf(real, 0.f);
-    int i0 = (int)floorf(real);
-    i0 = i0 < n_in - 1 ? i0 : n_in - 1;
-    float l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
-    SrcIdx s;
-    s.i0 = i0;
-    s.i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
-    s.w0 = 1.f - l1;
-    s.w1 = l1;
-    return s;
-}
-__device__ __forceinline__ float bilerp(const float* m, int Wn, const SrcIdx& sy, const SrcIdx& sx) {
-    const float a = m[(size_t)sy.i0 * Wn + sx.i0], b = m[(size_t)sy.i0 * Wn + sx.i1];
-    const float c = m[(size_t)sy.i1 * Wn + sx.i0], d = m[(size_t)sy.i1 * Wn + sx.i1];
-    const float top = sx.w0 * a + sx.w1 * b;        // every product and sum rounds on its own (fp contract is off in this file)
-    const float bot = sx.w0 * c + sx.w1 * d;
-    return sy.w0 * top + sy.w1 * bot;
+__device__ __forceinline__ float bilerp(const float* m, int Wn, const SrcIdx& sy, const SrcIdx& sx) {      // src_index / bilerp4: mask_interp.h
+    return bilerp4(m[(size_t)sy.i0 * Wn + sx.i0], m[(size_t)sy.i0 * Wn + sx.i1], m[(size_t)sy.i1 * Wn + sx.i0], m[(size_t)sy.i1 * Wn + sx.i1], sy, sx);
 }
 
 constexpr int MR_RPT = 8;     // output rows per thread
@@ -56,6 +36,66 @@ __global__ __launch_bounds__(256) void mask_resize_kernel(const float* __restric
         if (y >= H) break;
         float v = 0.f;
         if (y < ho && x < wo) v = bilerp(mn, Wn, src_index(y, Hn, rscale), sx);
+        const size_t o = ((size_t)n * H + y) * W + x;
+        if (outF) outF[o] = v;
+        if (outU) outU[o] = v > thr ? 1 : 0;
+    }
+}
+
+// CondInst scores -> masks at the ORIGINAL resolution in one pass (the MOTS loop never looks at the network-size maps): the factor-f aligned
+// bilinear of the coarse (h, w) sigmoid scores (= condinst_final_kernel, utils/boxes.py:138-146 / dynamic_mask_head.py:159-170) and the 1 / r
+// bilinear resize + `> thr` (= mask_resize_kernel, mot_evaluator.py:804-805) are chained through LDS instead of through an
+// (n, f h, f w) fp32 tensor in HBM (262 MB written + read back for 64 candidates at 800 x 1280).  A block owns a 64 x 32 output tile of one
+// instance: phase 1 evaluates ab_sample() for the window of network-grid samples the tile's bilinear taps touch (each sample once:
+// ~1100 samples for 2048 outputs at 1080p), phase 2 interpolates them with bilerp4().  Same inline functions and contraction modes as the
+// two kernels it replaces (mask_interp.h): bit-identical outputs.  Windows that do not fit the LDS (strong down-scaling) take the
+// sample-per-tap path.
+constexpr int CR_TX = 64, CR_TY = 32, CR_LDS = 12288;      // output tile, floats of LDS (48 KiB)
+__global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __restrict__ coarse, int h, int w, int f, float rscale, int ho, int wo,
+                                                              int H, int W, float thr, float* __restrict__ outF, unsigned char* __restrict__ outU) {
+    __shared__ float win[CR_LDS];
+    const int n = blockIdx.z, x0t = blockIdx.x * CR_TX, y0t = blockIdx.y * CR_TY;
+    const float* s = coarse + (size_t)n * h * w;
+    const int Hn = f * h, Wn = f * w;
+    const int tx = threadIdx.x & (CR_TX - 1), tg = threadIdx.x / CR_TX;          // 64 columns x 4 groups of 8 rows
+    const int x = x0t + tx;
+    int r0 = 0, c0 = 0, wh = 0, ww = 0;
+    const bool any = y0t < ho && x0t < wo;            // block-uniform: the tile holds interpolated pixels at all
+    if (any) {
+        const int yl = min(y0t + CR_TY, ho) - 1, xl = min(x0t + CR_TX, wo) - 1;
+        r0 = src_index(y0t, Hn, rscale).i0;          // src_index is monotonic in d: the taps of the tile lie in [r0, r1] x [c0, c1]
+        c0 = src_index(x0t, Wn, rscale).i0;
+        wh = src_index(yl, Hn, rscale).i1 - r0 + 1;
+        ww = src_index(xl, Wn, rscale).i1 - c0 + 1;
+    }
+    const bool staged = any && wh * ww <= CR_LDS;
+    if (staged) {
+        for (int i = threadIdx.x; i < wh * ww; i += 256) {
+            const int yy = i / ww, xx = i - yy * ww;
+            win[i] = ab_sample(s, h, w, f, r0 + yy, c0 + xx);
+        }
+    }
+    __syncthreads();
+    if (x >= W) return;
+    SrcIdx sx{};
+    if (x < wo) sx = src_index(x, Wn, rscale);
+#pragma unroll
+    for (int r = 0; r < CR_TY / 4; ++r) {
+        const int y = y0t + tg * (CR_TY / 4) + r;
+        if (y >= H) break;
+        float v = 0.f;
+        if (y < ho && x < wo) {
+            const SrcIdx sy = src_index(y, Hn, rscale);
+            if (staged) {
+                const float* p0 = win + (sy.i0 - r0) * ww + (sx.i0 - c0);
+                const float* p1 = win + (sy.i1 - r0) * ww + (sx.i0 - c0);
+                const int dx = sx.i1 - sx.i0;
+                v = bilerp4(p0[0], p0[dx], p1[0], p1[dx], sy, sx);
+            } else {
+                v = bilerp4(ab_sample(s, h, w, f, sy.i0, sx.i0), ab_sample(s, h, w, f, sy.i0, sx.i1), ab_sample(s, h, w, f, sy.i1, sx.i0),
+                            ab_sample(s, h, w, f, sy.i1, sx.i1), sy, sx);
+            }
+        }
         const size_t o = ((size_t)n * H + y) * W + x;
         if (outF) outF[o] = v;
         if (outU) outU[o] = v > thr ? 1 : 0;
@@ -182,20 +222,29 @@ __global__ __launch_bounds__(256) void rle_count_kernel(const unsigned char* __r
     (void)block_excl_scan(c, &total, sh);
     if (threadIdx.x == 0) tile_cnt[(size_t)n * ntiles + tile] = total;
 }
-// exclusive scan of a per-mask int array of length len (one block per mask, sequential over 256-wide chunks)
+// exclusive scan of a per-mask int array of length len: one block per mask, 16 consecutive elements per thread (a serial scan in registers +
+// ONE block scan of the thread sums per 4096 elements).  The first version walked 256 elements per block scan: 65 chunks x 3 barriers for the
+// 16385 run slots of a mask = 2 x 49 us per MOTS frame, now 5 chunks.
+constexpr int SCAN_E = 16;
 __global__ __launch_bounds__(256) void rle_scan_kernel(int* __restrict__ v, int len, int stride, int* __restrict__ totals) {
     __shared__ int sh[5];
     __shared__ int carry;
     int* p = v + (size_t)blockIdx.x * stride;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < len; base += 256) {
-        const int i = base + threadIdx.x;
-        const int x = i < len ? p[i] : 0;
+    for (int base = 0; base < len; base += 256 * SCAN_E) {
+        const int i0 = base + threadIdx.x * SCAN_E;
+        int x[SCAN_E], sum = 0;
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) x[e] = i0 + e < len ? p[i0 + e] : 0;
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) { const int t = x[e]; x[e] = sum; sum += t; }
         int total;
-        const int ex = block_excl_scan(x, &total, sh);
+        const int ex = block_excl_scan(sum, &total, sh);
         const int cbase = carry;
-        if (i < len) p[i] = cbase + ex;
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e)
+            if (i0 + e < len) p[i0 + e] = cbase + ex + x[e];
         __syncthreads();
         if (threadIdx.x == 0) carry = cbase + total;
         __syncthreads();
@@ -280,6 +329,13 @@ int launch_mask_resize(const float* masks, int N, int Hn, int Wn, float rscale, 
     if (N == 0) return 0;
     UNI_REQUIRE(Hn > 0 && Wn > 0 && H > 0 && W > 0 && ho > 0 && wo > 0 && N <= 65535 && H <= 65535, "mask_resize: bad geometry");
     hipLaunchKernelGGL(mask_resize_kernel, dim3(cdiv(W, 256), cdiv(H, MR_RPT), N), dim3(256), 0, s, masks, N, Hn, Wn, rscale, ho, wo, H, W, thr, outF, outU);
+    return 0;
+}
+int launch_condinst_resize(const float* coarse, int N, int h, int w, int f, float rscale, int ho, int wo, int H, int W, float thr, float* outF,
+                           unsigned char* outU, hipStream_t s) {
+    if (N == 0) return 0;
+    UNI_REQUIRE(h > 0 && w > 0 && f >= 1 && H > 0 && W > 0 && ho > 0 && wo > 0 && N <= 65535 && cdiv(H, CR_TY) <= 65535, "condinst_resize: bad geometry");
+    hipLaunchKernelGGL(condinst_resize_kernel, dim3(cdiv(W, CR_TX), cdiv(H, CR_TY), N), dim3(256), 0, s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU);
     return 0;
 }
 int launch_vos_merge(const float* probs, const int* prob_ids, int K1, int Hn, int Wn, float rscale, int ho, int wo,

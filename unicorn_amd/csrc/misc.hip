@@ -1,6 +1,7 @@
 // Small HBM-bound glue kernels of the path: casts, PixelShuffle, prior pyramid, box decode, position
 // embedding resize, aligned-bilinear upsample-add, instance-embedding sampling, CondInst dynamic mask head.
 #include "kernels.h"
+#include "mask_interp.h"
 
 // ------------------------------------------------------------------------------------------------
 // fp32 rows -> GEMM operand rows in the context's operand format (`b32`: FMT_H2 f16x2 hi/lo groups -- the headline --, FMT_F32 or FMT_BF16);
@@ -118,15 +119,6 @@ int launch_decode(const float* raw, float* out, int A0, int W0, int A1, int W1, 
 }
 
 // condinst/comm.py:5-27 aligned_bilinear(src, factor), accumulated into dst (mask_branch.py:80-93): dst += up(src)
-__device__ __forceinline__ void ab_coord(int o, int f, int n, int& i0, int& i1, float& fr) {
-    int t = o - f / 2;
-    t = t < 0 ? 0 : t;
-    float pos = (float)t / (float)f;
-    int a = (int)pos;
-    fr = pos - a;
-    i0 = a < n - 1 ? a : n - 1;
-    i1 = a + 1 < n - 1 ? a + 1 : n - 1;
-}
 __global__ void add_aligned_bilinear_kernel(const float* src, int h, int w, int C, int f, float* dst) {
     const int H = f * h, W = f * w, C4 = C >> 2;
     const long total = (long)H * W * C4;
@@ -332,13 +324,7 @@ __global__ __launch_bounds__(256) void condinst_final_kernel(CondInstArgs p) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Ho * Wo) return;
     const int y = e / Wo, x = e - y * Wo;
-    int y0, y1, x0, x1;
-    float fy, fx;
-    ab_coord(y, f, h, y0, y1, fy);
-    ab_coord(x, f, w, x0, x1, fx);
-    const float* s = p.coarse_ws + (size_t)inst * h * w;
-    p.out[(size_t)inst * Ho * Wo + e] = (1 - fy) * ((1 - fx) * s[y0 * w + x0] + fx * s[y0 * w + x1]) +
-                                        fy * ((1 - fx) * s[y1 * w + x0] + fx * s[y1 * w + x1]);
+    p.out[(size_t)inst * Ho * Wo + e] = ab_sample(p.coarse_ws + (size_t)inst * h * w, h, w, f, y, x);      // mask_interp.h
 }
 
 int launch_condinst(const CondInstArgs& a, hipStream_t s) {
@@ -347,8 +333,7 @@ int launch_condinst(const CondInstArgs& a, hipStream_t s) {
     const int hw = a.H * a.W, rr = a.r * a.r;
     hipLaunchKernelGGL(condinst_mlp_kernel, dim3(cdiv(hw, 256), a.n), dim3(256), 0, s, a);
     hipLaunchKernelGGL(condinst_upsample_kernel, dim3(cdiv(hw * rr, 256), a.n), dim3(256), 0, s, a);
-    const float* coarse = a.coarse_ws;
-    (void)coarse;
+    if (!a.out) return 0;          // the caller continues from coarse_ws (uni_condinst_masks_u8: fused upsample + resize, mask_post.hip)
     if (a.d_rate == 1) {
         UNI_CHECK_HIP(hipMemcpyAsync(a.out, a.coarse_ws, (size_t)a.n * hw * rr * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {

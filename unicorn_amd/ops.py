@@ -149,6 +149,27 @@ def condinst_masks(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_
     return out
 
 
+def condinst_masks_resized(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_rate, r, H, W, thr=None):
+    """condinst_masks + mask_resize in ONE call (uni_condinst_masks_u8): the CondInst scores of `params` resized by 1/r and pasted into
+    (N, H, W) maps -- `> thr` bytes (mot_evaluator.py:804-805) or, with thr=None, fp32 probabilities (unicorn_vos.py:141-152) -- without the
+    (N, 1, Hn, Wn) network-size maps ever reaching HBM.  Bit-identical to mask_resize(condinst_masks(...)[:, 0], r, H, W, thr)."""
+    _need_cuda(mask_feats, up_masks, params)
+    mf, um = nhwc(mask_feats), nhwc(up_masks)
+    _, _, H8, W8 = mf.shape
+    p = params.float().contiguous()
+    n = p.shape[0]
+    out = torch.empty((n, int(H), int(W)), device=mf.device, dtype=torch.float32 if thr is None else torch.uint8)
+    if n:
+        loc = inst_loc.float().contiguous().to(mf.device)
+        lvl = inst_lvl.to(device=mf.device, dtype=torch.int32).contiguous()
+        ws = torch.empty(n * H8 * W8 * (1 + up_rate * up_rate), device=mf.device, dtype=torch.float32)
+        L.check(L.lib().uni_condinst_masks_u8(L.ptr(mf), L.ptr(um), L.ptr(p), p.shape[1], L.ptr(loc), L.ptr(lvl), n, H8, W8, up_rate, d_rate,
+                                              float(r), int(H), int(W), 0.0 if thr is None else float(thr), L.ptr(out) if thr is None else None,
+                                              None if thr is None else L.ptr(out), L.ptr(ws), ws.numel() * 4, L.stream_ptr()),
+                "uni_condinst_masks_u8")
+    return out
+
+
 _post_ws = {}
 
 

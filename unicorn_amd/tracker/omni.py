@@ -34,7 +34,7 @@ import torch
 
 from ..ops import (condinst_masks, mots_overlap_free, nhwc, postprocess_collect, postprocess_launch, rle_encode_collect,
                    rle_encode_launch, sample_embeddings)
-from ..utils.masks import mots_threshold
+from ..utils.masks import mots_condinst_threshold, mots_threshold
 from ..utils.timing import NoTimer
 
 
@@ -215,6 +215,7 @@ class OmniMOTSFrame(OmniMOTFrame):
                  d_rate=2, min_box_area=100, timer=None):
         super().__init__(model, tracker, img_size, num_classes, confthre, nmsthre, embed_score_thr, timer)
         self.mask_thres, self.d_rate, self.min_box_area = mask_thres, d_rate, min_box_area  # :805, exp.d_rate, args.min_box_area
+        self.fused_masks = True      # False: the two-pass path (network-size fp32 masks of the reference API, then uni_mask_resize): A/B + tests
         self._levels_dev = {}
 
     def _stage_b(self, tk):
@@ -232,6 +233,10 @@ class OmniMOTSFrame(OmniMOTFrame):
         for b, (det, idx) in enumerate(sel):
             if det is None:
                 tk.masks.append(None)
+                continue
+            if self.fused_masks:      # CondInst -> 1/scale resize -> `> thr` bytes in one pass (uni_condinst_masks_u8): same bits, no fp32 maps
+                tk.masks.append(mots_condinst_threshold(mask_feats[b:b + 1], up_masks[b:b + 1], dyn[b][idx], locations[idx], lv_dev[b][idx],
+                                                        m.head.mask_head.up_rate, self.d_rate, scale, int(img_h), int(img_w), self.mask_thres))
                 continue
             om = condinst_masks(mask_feats[b:b + 1], up_masks[b:b + 1], dyn[b][idx], locations[idx], lv_dev[b][idx], m.head.mask_head.up_rate,
                                 self.d_rate)

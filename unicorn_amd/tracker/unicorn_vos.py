@@ -95,22 +95,27 @@ class UnicornVOSTrack:
         device | None}, instance scores.  (The resize to the original resolution is fused into the aggregation kernel.)"""
         det, msk = self.get_det_results(fpn, d_cur, d_pre, object_ids)
         probs, scores = {}, np.zeros((len(object_ids),))
+        # the best row of every object goes to the host in ONE copy (a `.cpu()` per object drains the stream K times per frame)
+        live = [k for k in object_ids if det[k] is not None]
+        rows = {}
+        if live:
+            top = torch.stack([det[k][0] for k in live])                                       # (n_live, 7): index-0 instance (:131-136)
+            top[:, 0:4:2] = top[:, 0:4:2].clamp(min=0, max=self.input_size[1])
+            top[:, 1:4:2] = top[:, 1:4:2].clamp(min=0, max=self.input_size[0])
+            host = top.cpu().numpy()
+            rows = {k: (top[i], host[i]) for i, k in enumerate(live)}
         for i, k in enumerate(object_ids):
-            d = det[k]
-            if d is None:
+            if k not in rows:
                 probs[k] = None
                 continue
-            d = d[:self.max_inst].clone()
-            d[:, 0:4:2] = d[:, 0:4:2].clamp(min=0, max=self.input_size[1])
-            d[:, 1:4:2] = d[:, 1:4:2].clamp(min=0, max=self.input_size[0])
-            dn = d.cpu().numpy()
-            b = dn[:, 0:4] / r
-            b[:, 2] -= b[:, 0]
-            b[:, 3] -= b[:, 1]
-            self.state_pre_dict[k] = [int(v) for v in b[0]]                                    # :137-139
-            scores[i] = dn[0, 4] * dn[0, 5]
+            d0, dn = rows[k]
+            b = dn[0:4] / r
+            b[2] -= b[0]
+            b[3] -= b[1]
+            self.state_pre_dict[k] = [int(v) for v in b]                                       # :137-139
+            scores[i] = dn[4] * dn[5]
             probs[k] = msk[k][0, 0]
-            self._last_det[k] = d[0]
+            self._last_det[k] = d0
         return probs, scores
 
     def step(self, image):

@@ -34,6 +34,22 @@ def mots_threshold(outputs_mask, scale, img_h, img_w, mask_thres=0.30, crop=True
     return out
 
 
+def mots_condinst_threshold(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_rate, scale, img_h, img_w, mask_thres=0.30, crop=True):
+    """postprocess_inst's masks (utils/boxes.py:138-146) + mots_threshold in one fused call: the arguments of ops.condinst_masks for the kept
+    detections of ONE image -> the uint8 masks mots_threshold(condinst_masks(...), scale, img_h, img_w, mask_thres, crop) returns, bit for
+    bit, without the (N, 1, Hn, Wn) fp32 maps (uni_condinst_masks_u8)."""
+    from ..ops import condinst_masks_resized
+    img_h, img_w = int(img_h), int(img_w)
+    out = condinst_masks_resized(mask_feats, up_masks, params, inst_loc, inst_lvl, up_rate, d_rate, scale, img_h, img_w, thr=mask_thres)
+    if crop and out.shape[0]:
+        import math
+        Hn, Wn = d_rate * up_rate * mask_feats.shape[2], d_rate * up_rate * mask_feats.shape[3]
+        ho, wo = min(img_h, int(math.floor(Hn * (1.0 / scale)))), min(img_w, int(math.floor(Wn * (1.0 / scale))))
+        if ho < img_h or wo < img_w:
+            out = out[:, :ho, :wo].contiguous()
+    return out
+
+
 def mots_rle(masks, order=None):
     """masks (N, H, W) uint8 in detection order, order: indices into masks in ascending-track-id order (after `indexs` /
     `valid_inds`, mot_evaluator.py:850-856).  Returns (overlap-free masks (M, H, W) uint8 on the device, list of M RLE strings)."""
