@@ -838,9 +838,38 @@ def main():
                                                        "upsample -> instance embeddings -> native QuasiDense match" % NB)
         # ---- tracker-level numbers (the reference drivers' own call pattern: one frame per call, host-synchronised), per-stage GPU ms
         from unicorn_amd.tracker import OmniMOTSFrame, QuasiDenseEmbedTracker, UnicornSOTTrack
+        from unicorn_amd.utils.timing import NoTimer as NoTimer_
         from unicorn_amd.utils.timing import StageTimer
         g_ = torch.Generator().manual_seed(3)
         raw = [torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, generator=g_).pin_memory() for _ in range(4)]
+
+        def ctx_roofline(model, fn, n=3):
+            """roofline block of a CONFIG (not only the SOT step): `fn(i)` = one call of the config's loop body; the engine's
+            per-launch HIP events (uni_prof_begin / uni_prof_end on the model's context, head levels serialised while profiling) give the
+            GEMM-class time and FLOPs and the HBM-bound classes' time and algorithmic bytes per call"""
+            import ctypes as C
+            buf = (C.c_double * 16)()
+            fn(0)
+            torch.cuda.synchronize()
+            L.check(L.lib().uni_prof_begin(model._ctx), "prof_begin")
+            for i in range(n):
+                fn(1 + i)
+            torch.cuda.synchronize()
+            L.check(L.lib().uni_prof_end(model._ctx, buf), "prof_end")
+            v = list(buf)
+            g_ms, g_work, g_n = v[0] / n, v[1] / n, v[2] / n
+            ach = g_work / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+            pk = {"bf16": 2500.0, "f16x2": round(2500.0 / 3, 1), "fp32": 157.3}[args.precision]
+            hb = {}
+            for i_, n_ in ((1, "dwconv7_ln"), (2, "gn_apply"), (3, "layernorm")):
+                ms_1 = v[3 * i_] / n
+                hb[n_] = {"ms_per_call": round(ms_1, 4), "GBps": round(v[3 * i_ + 1] / n / (ms_1 * 1e-3) / 1e9, 1) if ms_1 > 0 else 0,
+                          "frac": round(v[3 * i_ + 1] / n / (ms_1 * 1e-3) / 8e12, 4) if ms_1 > 0 else 0, "launches": v[3 * i_ + 2] / n}
+            return {"kernel": "GEMM class of this config (gemm_h2q / gemm_h2d / gemm_h2 / mlp_fused16 instantiations)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "frac_vs_f16_peak": round(ach / 2500.0, 4),
+                    "gemm_ms_per_call": round(g_ms, 4), "gemm_launches_per_call": g_n, "flops_per_call": g_work,
+                    "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "hbm": hb, "misc_ms_per_call": round(v[12] / n, 4),
+                    "note": "engine HIP events per launch (profiling mode: head levels and mask branch serialised); peak = 2500 / 3 MFMAs per f16x2 product"}
 
         def staged(run, timer, n=12, warm=2, stream=None, set_timer=None):
             """(1) one frame per call, host-synchronised per frame, with per-stage GPU / host ms (the reference loops' own pattern);
@@ -904,6 +933,10 @@ def main():
                                               stream=lambda k: sum(1 for _ in ms_.omni.run_stream((ms_.frames[1 + j % 4] for j in range(k)), (1080, 1920))),
                                               set_timer=lambda t_: setattr(ms_.omni, "t", t_))
             configs["mot_omni_loop"]["note"] = "mot_evaluator.py:991-1045 per frame on unicorn_track_large_mot_challenge, ~200 NMS candidates, native association"
+            ms_.omni.t = NoTimer_()
+            configs["mot_omni_loop"]["roofline"] = ctx_roofline(ms_.model, lambda i: ms_.omni.run(ms_.frames[1 + i % 4], (1080, 1920)))
+            ms_.omni.reset()
+            configs["large_mot_challenge_step"]["roofline"] = ctx_roofline(ms_.model, lambda i: ms_.omni.run_batch(ms_.batches[i % 4], (H, W)))
         del ms_
         torch.cuda.empty_cache()
         with torch.no_grad():      # (c) MOTS loop (mot_evaluator.py:770-890): CondInst masks, overlap-free merge, device RLE
@@ -924,12 +957,32 @@ def main():
                                           stream=lambda k: sum(1 for _ in mots.run_stream((mm_.frames[1 + j % 4] for j in range(k)), (1080, 1920))),
                                           set_timer=lambda t_: setattr(mots, "t", t_))
             configs["mots_loop"]["rle_strings_last_frame"] = nrle[0]
+            mots.t = NoTimer_()
+            configs["mots_loop"]["roofline"] = ctx_roofline(mm_.model, run_mots)
             configs["mots_loop"]["note"] = ("MOTS loop per frame on unicorn_track_large_mot_challenge_mask: postprocess_inst (64 candidates) + CondInst masks -> "
                                             "uni_mask_resize > thr at 1080p -> association -> uni_mots_overlap_free -> uni_rle_encode strings")
         del mm_, mots
         torch.cuda.empty_cache()
         vs, configs["large_vos_k3"] = quick("unicorn_track_large_mask", args.precision, "vos", 1, steps=6, warmup=2, keep=True)
         configs["large_vos_k3"]["note"] = "3 objects per frame: one backbone, per object correlation + head + CondInst masks + postprocess (UnicornVOSTrack.step)"
+        with torch.no_grad():
+            configs["large_vos_k3"]["roofline"] = ctx_roofline(vs.model, lambda i: vs.trk.step(vs.frames[1 + i % 4]))
+            # stage table of the VOS step (host-synchronised per stage, tools/vos_profile.py's cut): where the frame goes
+            def vt(fn_, n_=4):
+                fn_()
+                torch.cuda.synchronize()
+                t1_ = time.perf_counter()
+                for _ in range(n_):
+                    r_ = fn_()
+                torch.cuda.synchronize()
+                return round(1e3 * (time.perf_counter() - t1_) / n_, 3), r_
+            tr_ = vs.trk
+            st_ = {}
+            st_["backbone+fpn"], (fpn_, dcur_) = vt(lambda: vs.model(imgs=vs.frames[1], mode="backbone"))
+            st_["group: interaction + 2 x upsample + correlation (K rows) + head (K objects) + postprocess_inst + CondInst"], _ = vt(
+                lambda: tr_.get_mask_results(fpn_, dcur_, tr_.out_dict_pre, 1.0, tr_.init_object_ids))
+            st_["whole step (UnicornVOSTrack.step)"], _ = vt(lambda: tr_.step(vs.frames[1]))
+            configs["large_vos_k3"]["stages_ms_host_synchronised"] = st_
         if not args.no_cpu_baseline:      # mask parity of the VOS config on one frame (oracle loop over the 3 objects)
             with torch.no_grad():
                 res, _ = vs.trk.step(vs.frames[1])

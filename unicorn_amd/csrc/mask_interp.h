@@ -10,21 +10,26 @@
 __device__ __forceinline__ void ab_coord(int o, int f, int n, int& i0, int& i1, float& fr) {
     int t = o - f / 2;
     t = t < 0 ? 0 : t;
-    float pos = (float)t / (float)f;
+    // t / f in fp32; for a power-of-two factor (d_rate = 1, 2, 4: every configuration of the reference) the product with the exact
+    // reciprocal is the same number, and the reciprocal is loop-invariant (one division per thread instead of one per sample)
+    const float pos = (f & (f - 1)) == 0 ? (float)t * (1.0f / (float)f) : (float)t / (float)f;
     int a = (int)pos;
     fr = pos - a;
     i0 = a < n - 1 ? a : n - 1;
     i1 = a + 1 < n - 1 ? a + 1 : n - 1;
 }
-// value of the factor-f aligned-bilinear upsample of s (h x w) at output pixel (y, x); contraction allowed, exactly as
-// condinst_final_kernel has always been compiled (hipcc's default)
-__device__ __forceinline__ float ab_sample(const float* __restrict__ s, int h, int w, int f, int y, int x) {
+// value of the factor-f aligned-bilinear upsample of s (rows of w samples) from its coordinates; contraction allowed, exactly as
+// condinst_final_kernel has always been compiled (hipcc's default).  ONE definition for the two-pass and the fused kernel.
+__device__ __forceinline__ float ab_value(const float* __restrict__ row0, const float* __restrict__ row1, int x0, int x1, float fy, float fx) {
 #pragma clang fp contract(fast)
+    return (1 - fy) * ((1 - fx) * row0[x0] + fx * row0[x1]) + fy * ((1 - fx) * row1[x0] + fx * row1[x1]);
+}
+__device__ __forceinline__ float ab_sample(const float* __restrict__ s, int h, int w, int f, int y, int x) {
     int y0, y1, x0, x1;
     float fy, fx;
     ab_coord(y, f, h, y0, y1, fy);
     ab_coord(x, f, w, x0, x1, fx);
-    return (1 - fy) * ((1 - fx) * s[y0 * w + x0] + fx * s[y0 * w + x1]) + fy * ((1 - fx) * s[y1 * w + x0] + fx * s[y1 * w + x1]);
+    return ab_value(s + y0 * w, s + y1 * w, x0, x1, fy, fx);
 }
 
 // ATen UpSample.h: area_pixel_compute_source_index (align_corners = false) + guard_index_and_lambda, fp32; NO contraction: every

@@ -8,6 +8,7 @@
 //   rle_*                  pycocotools rleEncode (column-major runs) + rleToString (mot_evaluator.py:889-892)
 // HBM-bound streaming kernels: coalesced along x, one pass over the inputs.
 #include "kernels.h"
+#include <cstdlib>
 #include "mask_interp.h"
 
 // the float arithmetic below must round exactly like the numpy restatement: no fused multiply-add anywhere in this file
@@ -51,9 +52,10 @@ __global__ __launch_bounds__(256) void mask_resize_kernel(const float* __restric
 // two kernels it replaces (mask_interp.h): bit-identical outputs.  Windows that do not fit the LDS (strong down-scaling) take the
 // sample-per-tap path.
 constexpr int CR_TX = 64, CR_TY = 32, CR_LDS = 12288;      // output tile, floats of LDS (48 KiB)
+template <bool STAGED>
 __global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __restrict__ coarse, int h, int w, int f, float rscale, int ho, int wo,
-                                                              int H, int W, float thr, float* __restrict__ outF, unsigned char* __restrict__ outU) {
-    __shared__ float win[CR_LDS];
+                                                              int H, int W, float thr, float* __restrict__ outF, unsigned char* __restrict__ outU, int dbg) {
+    extern __shared__ float win[];                    // STAGED: the launcher's bound on a tile's window (<= CR_LDS floats; 4.3 KB at 1080p: 8 blocks per CU)
     const int n = blockIdx.z, x0t = blockIdx.x * CR_TX, y0t = blockIdx.y * CR_TY;
     const float* s = coarse + (size_t)n * h * w;
     const int Hn = f * h, Wn = f * w;
@@ -68,14 +70,74 @@ __global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __res
         wh = src_index(yl, Hn, rscale).i1 - r0 + 1;
         ww = src_index(xl, Wn, rscale).i1 - c0 + 1;
     }
-    const bool staged = any && wh * ww <= CR_LDS;
-    if (staged) {
-        for (int i = threadIdx.x; i < wh * ww; i += 256) {
-            const int yy = i / ww, xx = i - yy * ww;
-            win[i] = ab_sample(s, h, w, f, r0 + yy, c0 + xx);
+    const bool staged = STAGED && any;              // (the launcher picks STAGED only when every tile's window fits: wh * ww <= CR_LDS)
+    if (staged && !(dbg & 1)) {      // a thread keeps its window column(s): the x coordinates once, no integer division per sample
+        for (int xx = tx; xx < ww; xx += CR_TX) {
+            int x0, x1;
+            float fx;
+            ab_coord(c0 + xx, f, w, x0, x1, fx);
+#pragma unroll 4
+            for (int yy = tg; yy < wh; yy += 256 / CR_TX) {      // (unrolled: the loads of four samples are in flight together)
+                int y0, y1;
+                float fy;
+                ab_coord(r0 + yy, f, h, y0, y1, fy);
+                win[__mul24(yy, ww) + xx] = ab_value(s + __mul24(y0, w), s + __mul24(y1, w), x0, x1, fy, fx);     // (24-bit products: full-rate integer multiplies)
+            }
         }
     }
-    __syncthreads();
+    if (STAGED) {
+        // phase 2: a thread owns 4 consecutive x of 2 rows (16 x-groups x 16 row pairs): the four column taps once, one packed 4-byte
+        // store per row -- the first version (one x, 8 rows, byte stores) spent ~110 VALU instructions per pixel on source indices and
+        // 64-bit output addresses and ran at the speed of the two passes it replaces (440 us for 64 masks at 1080p)
+        __syncthreads();
+        const int qx = threadIdx.x & 15, qy = threadIdx.x >> 4;
+        const int xb = x0t + 4 * qx;
+        if (xb >= W) return;
+        int co[4], dx[4];
+        float wx0[4], wx1[4];
+        bool inx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            inx[e] = xb + e < wo;
+            const SrcIdx q = src_index(inx[e] ? xb + e : 0, Wn, rscale);
+            co[e] = inx[e] ? q.i0 - c0 : 0; dx[e] = inx[e] ? q.i1 - q.i0 : 0; wx0[e] = q.w0; wx1[e] = q.w1;
+        }
+        const bool packed = (W & 3) == 0;
+        const size_t blk0 = ((size_t)n * H + y0t) * W + x0t;       // block-uniform 64-bit part of the output offset (scalar unit)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0t + 2 * qy + r;
+            if (y >= H) break;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y < ho) {
+                const SrcIdx sy = src_index(y, Hn, rscale);
+                const float* p0 = win + __mul24(sy.i0 - r0, ww);
+                const float* p1 = win + __mul24(sy.i1 - r0, ww);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (inx[e]) {
+                        SrcIdx sxe; sxe.i0 = 0; sxe.i1 = 0; sxe.w0 = wx0[e]; sxe.w1 = wx1[e];
+                        v[e] = bilerp4(p0[co[e]], p0[co[e] + dx[e]], p1[co[e]], p1[co[e] + dx[e]], sy, sxe);
+                    }
+            }
+            const size_t o = blk0 + (unsigned)(__mul24(2 * qy + r, W) + 4 * qx);
+            if (outF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (xb + e < W) outF[o + e] = v[e];
+            }
+            if (outU && !((dbg & 2) && v[0] != 12345.f)) {
+                if (packed) {
+                    *reinterpret_cast<unsigned*>(outU + o) = (v[0] > thr ? 1u : 0u) | (v[1] > thr ? 0x100u : 0u) | (v[2] > thr ? 0x10000u : 0u) | (v[3] > thr ? 0x1000000u : 0u);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (xb + e < W) outU[o + e] = v[e] > thr ? 1 : 0;
+                }
+            }
+        }
+        return;
+    }
     if (x >= W) return;
     SrcIdx sx{};
     if (x < wo) sx = src_index(x, Wn, rscale);
@@ -84,18 +146,10 @@ __global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __res
         const int y = y0t + tg * (CR_TY / 4) + r;
         if (y >= H) break;
         float v = 0.f;
-        if (y < ho && x < wo) {
-            const SrcIdx sy = src_index(y, Hn, rscale);
-            if (staged) {
-                const float* p0 = win + (sy.i0 - r0) * ww + (sx.i0 - c0);
-                const float* p1 = win + (sy.i1 - r0) * ww + (sx.i0 - c0);
-                const int dx = sx.i1 - sx.i0;
-                v = bilerp4(p0[0], p0[dx], p1[0], p1[dx], sy, sx);
-            } else {
-                v = bilerp4(ab_sample(s, h, w, f, sy.i0, sx.i0), ab_sample(s, h, w, f, sy.i0, sx.i1), ab_sample(s, h, w, f, sy.i1, sx.i0),
-                            ab_sample(s, h, w, f, sy.i1, sx.i1), sy, sx);
-            }
-        }
+        if (y < ho && x < wo)
+            v = bilerp4(ab_sample(s, h, w, f, src_index(y, Hn, rscale).i0, sx.i0), ab_sample(s, h, w, f, src_index(y, Hn, rscale).i0, sx.i1),
+                        ab_sample(s, h, w, f, src_index(y, Hn, rscale).i1, sx.i0), ab_sample(s, h, w, f, src_index(y, Hn, rscale).i1, sx.i1),
+                        src_index(y, Hn, rscale), sx);
         const size_t o = ((size_t)n * H + y) * W + x;
         if (outF) outF[o] = v;
         if (outU) outU[o] = v > thr ? 1 : 0;
@@ -335,7 +389,14 @@ int launch_condinst_resize(const float* coarse, int N, int h, int w, int f, floa
                            unsigned char* outU, hipStream_t s) {
     if (N == 0) return 0;
     UNI_REQUIRE(h > 0 && w > 0 && f >= 1 && H > 0 && W > 0 && ho > 0 && wo > 0 && N <= 65535 && cdiv(H, CR_TY) <= 65535, "condinst_resize: bad geometry");
-    hipLaunchKernelGGL(condinst_resize_kernel, dim3(cdiv(W, CR_TX), cdiv(H, CR_TY), N), dim3(256), 0, s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU);
+    // window of a tile: taps of CR_TY (CR_TX) consecutive outputs span at most ceil((CR_TY - 1) * rscale) + 3 source rows (columns)
+    const long wh = (long)ceilf((CR_TY - 1) * rscale) + 3, ww = (long)ceilf((CR_TX - 1) * rscale) + 3;
+    const dim3 grid(cdiv(W, CR_TX), cdiv(H, CR_TY), N);
+    // dynamic LDS = the window bound, not the 48 KiB maximum: a block lives for ~5 dependent L2 round trips (phase 1), so the kernel is bound
+    // by the blocks in flight per CU (3 with a static 48 KiB array: 345 us for 64 masks; 8 with 4.3 KiB)
+    static const int dbg = getenv("UNI_CR_DBG") ? atoi(getenv("UNI_CR_DBG")) : 0;      // ablation (tools/mask_bench.py): 1 = no window evaluation, 2 = no byte stores
+    if (wh * ww <= CR_LDS) hipLaunchKernelGGL(condinst_resize_kernel<true>, grid, dim3(256), (size_t)(wh * ww) * sizeof(float), s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU, dbg);
+    else hipLaunchKernelGGL(condinst_resize_kernel<false>, grid, dim3(256), 0, s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU, dbg);
     return 0;
 }
 int launch_vos_merge(const float* probs, const int* prob_ids, int K1, int Hn, int Wn, float rscale, int ho, int wo,
