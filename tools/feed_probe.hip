@@ -154,7 +154,10 @@ static void run_gemm(const char* buf, unsigned* sink, int M, int N, int K, int p
 // SIMD) -- does a second wave per SIMD take the VMEM issue stalls off the MFMA stream?
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-template <bool SPEC, int DEPTH>
+// WB = 1: the weight panel is stored K-BLOCKED in granules of 32 rows x one 32-k slice (4 KiB contiguous; a 1-KiB request = 8 consecutive
+// 128-B rows of one granule is ONE contiguous KiB instead of 8 lines a row stride apart): granule (n / 32, kt) at ((n / 32) * nk + kt) * 4096.
+// AB = 1: the same for the activation panel (what a producing kernel would have to write).
+template <bool SPEC, int DEPTH, int WB = 0, int AB = 0>
 __global__ __launch_bounds__(SPEC ? 512 : 256, 1) void gemm_mix_kernel(const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ sink, int M, int N,
                                                                        int nk, int sa, int sw) {
     constexpr int BM = 128, BN = 96, A_PC = 4, B_PC = 3, PER = 7;
@@ -172,15 +175,21 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 1) void gemm_mix_kernel(const cha
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(W) + (size_t)bn * BN * sw, 0, min(BN, N - bn * BN) * sw, 0x00020000);
     int voa[8], vob[8];
 #pragma unroll
-    for (int i = 0; i < A_PC; ++i) voa[i] = (8 * (pw + 4 * i) + (lane >> 3)) * sa + (lane & 7) * 16;
+    for (int i = 0; i < A_PC; ++i) {
+        const int r = 8 * (pw + 4 * i) + (lane >> 3);
+        voa[i] = AB ? (r >> 5) * (nk * 4096) + (r & 31) * 128 + (lane & 7) * 16 : r * sa + (lane & 7) * 16;
+    }
 #pragma unroll
-    for (int i = 0; i < B_PC; ++i) vob[i] = (8 * (pw + 4 * i) + (lane >> 3)) * sw + (lane & 7) * 16;
+    for (int i = 0; i < B_PC; ++i) {
+        const int r = 8 * (pw + 4 * i) + (lane >> 3);
+        vob[i] = WB ? (r >> 5) * (nk * 4096) + (r & 31) * 128 + (lane & 7) * 16 : r * sw + (lane & 7) * 16;
+    }
     auto issue = [&](int kt, int slot, bool live) __attribute__((always_inline)) {
         char* dst = smem + slot * (BM + BN) * 128 + pw * 1024;
 #pragma unroll
-        for (int i = 0; i < A_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, live ? voa[i] : 0x7fffffff, kt * 128, 0, 0);
+        for (int i = 0; i < A_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, live ? voa[i] : 0x7fffffff, kt * (AB ? 4096 : 128), 0, 0);
 #pragma unroll
-        for (int i = 0; i < B_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + BM * 128 + i * 4096), 16, live ? vob[i] : 0x7fffffff, kt * 128, 0, 0);
+        for (int i = 0; i < B_PC; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + BM * 128 + i * 4096), 16, live ? vob[i] : 0x7fffffff, kt * (WB ? 4096 : 128), 0, 0);
     };
     f32x16 acc[3];
 #pragma unroll
@@ -267,27 +276,27 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 1) void gemm_mix_kernel(const cha
     if (t == 1234.5f) sink[0] = t;
 }
 
-template <bool SPEC, int DEPTH>
+template <bool SPEC, int DEPTH, int WB = 0, int AB = 0>
 static void run_mix(const char* buf, float* sink, int M, int N, int K) {
     const int sa = K * 4, sw = K * 4, nk = K / 32;
     const char* A = buf;
     const char* W = buf + (((size_t)M * sa + 4095) & ~(size_t)4095);
     const int grid = ((M + 127) / 128) * ((N + 95) / 96);
     const size_t lds = (size_t)DEPTH * (128 + 96) * 128;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mix_kernel<SPEC, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mix_kernel<SPEC, DEPTH, WB, AB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 6; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((gemm_mix_kernel<SPEC, DEPTH>), dim3(grid), dim3(SPEC ? 512 : 256), lds, 0, A, W, sink, M, N, nk, sa, sw);
+        hipLaunchKernelGGL((gemm_mix_kernel<SPEC, DEPTH, WB, AB>), dim3(grid), dim3(SPEC ? 512 : 256), lds, 0, A, W, sink, M, N, nk, sa, sw);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
-    printf("gemm feed + MFMA %5d x %4d x %4d  tile 128 x 96 (%3d blocks)  %d deep  %s: %7.1f us  (%.0f TF-eq of f16x2 products)\n", M, N, K, grid, DEPTH,
-           SPEC ? "8 waves: 4 consumers + 4 producers" : "4 waves, DMA issued between the MFMAs  ", best * 1e3, 2.0 * M * N * K / best / 1e9);
+    printf("gemm feed + MFMA %5d x %4d x %4d  tile 128 x 96 (%3d blocks)  %d deep  W %s A %s  %s: %7.1f us  (%.0f TF-eq of f16x2 products)\n", M, N, K, grid, DEPTH,
+           WB ? "K-blocked" : "row-major", AB ? "K-blocked" : "row-major", SPEC ? "8 waves: 4 consumers + 4 producers" : "4 waves, DMA issued between the MFMAs  ", best * 1e3, 2.0 * M * N * K / best / 1e9);
 }
 
 int main(int argc, char** argv) {
@@ -314,9 +323,12 @@ int main(int argc, char** argv) {
     run<3, 4, 8>(src, sink, win, nblk);
     if (argc > 3) {
         char* big;
-        hipMalloc(&big, (size_t)512 << 20);
-        hipMemset(big, 1, (size_t)512 << 20);
+        hipMalloc(&big, (size_t)1088 << 20);      // the 64000 x 3072 f16x2 panel is 786 MB
+        hipMemset(big, 1, (size_t)1088 << 20);
         run_mix<false, 4>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<false, 4, 1>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<false, 4, 1, 1>(big, (float*)sink, 4000, 768, 3072);
+        run_mix<true, 4, 1, 1>(big, (float*)sink, 4000, 768, 3072);
         run_mix<true, 4>(big, (float*)sink, 4000, 768, 3072);
         run_mix<false, 3>(big, (float*)sink, 4000, 768, 3072);
         run_mix<true, 5>(big, (float*)sink, 4000, 768, 3072);
@@ -330,14 +342,9 @@ int main(int argc, char** argv) {
         run_gemm<128, 96, 3, true>(big, sink, 4000, 768, 3072, 0, 0);
         run_gemm<128, 96, 6, true>(big, sink, 4000, 768, 3072, 0, 0);
         run_gemm<128, 96, 8, true>(big, sink, 4000, 768, 3072, 0, 0);
-        run_gemm<128, 96, 8, true>(big, sink, 4000, 768, 3072, 128, 128);
-        run_gemm<128, 96, 8, false>(big, sink, 4000, 768, 3072, 128, 128);
         for (auto& pd : pads) run_gemm<256, 192, 2, true>(big, sink, 4000, 3072, 768, pd[0], pd[1]);   // stage-2 pwconv1 of one frame (cfg 346)
-        run_gemm<256, 192, 3, true>(big, sink, 4000, 3072, 768, 0, 0);
-        run_gemm<256, 192, 3, true>(big, sink, 4000, 3072, 768, 128, 128);
         for (auto& pd : pads) run_gemm<64, 64, 3, true>(big, sink, 4000, 768, 3072, pd[0], pd[1]);
         run_gemm<64, 64, 8, true>(big, sink, 4000, 768, 3072, 0, 0);
-        run_gemm<64, 64, 8, true>(big, sink, 4000, 768, 3072, 128, 128);
         // 16 frames: stage-2 pwconv1 / pwconv2 on 256 x 256 tiles (gemm_h2q: 2 stages)
         for (auto& pd : pads) run_gemm<256, 256, 2, true>(big, sink, 64000, 3072, 768, pd[0], pd[1]);
         for (auto& pd : pads) run_gemm<256, 256, 2, true>(big, sink, 64000, 768, 3072, pd[0], pd[1]);
