@@ -1083,7 +1083,7 @@ def test_mots_threshold_matches_reference_crop_shape():
     assert tuple(full.shape) == (3, img_h, img_w) and not full[:, :, img_w - 1:].any()
 
 
-@pytest.mark.parametrize("cfg", [322, 323, 332, 331, 346])
+@pytest.mark.parametrize("cfg", [322, 323, 332, 331, 346, 422, 423])      # 422 / 423: 322 / 323 with producer waves (round 5)
 @pytest.mark.parametrize("case", [
     # (Hin, Win, Cin, N, k, stride, pad, act, res, stats_G, outB, splitk)
     (4000, 1, 3072, 768, 1, 1, 0, 0, True, 0, False, 1),      # stage-2 pwconv2 of one frame + in-place residual (256 tiles of 128 x 96)

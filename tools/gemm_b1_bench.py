@@ -23,7 +23,7 @@ SHAPES = [
     ("1x1 16000x1024x256", 16000, 1, 256, 1024, 1, 0, 0, 0), ("1x1 4000x768x768", 4000, 1, 768, 768, 1, 0, 0, 0),
     ("1x1 16000x192x192", 16000, 1, 192, 192, 1, 0, 0, 0), ("1x1 4000x256x1024", 4000, 1, 1024, 256, 1, 0, 0, 0),
 ]
-CFGS = [int(v) for v in os.environ.get("CFGS", "0,188,22,11,322,323,332,331").split(",")]
+CFGS = [int(v) for v in os.environ.get("CFGS", "0,188,22,11,322,323,332,331,422,423").split(",")]
 SPLITS = [int(v) for v in os.environ.get("SPLITS", "1,2,3,4").split(",")]
 SPLIT_CFGS = tuple(int(v) for v in os.environ.get("SPLIT_CFGS", "188,22,323,331").split(","))
 if os.environ.get("ONLY"):

@@ -31,9 +31,19 @@ __device__ __forceinline__ void d_wait_vm() {
 }
 }  // namespace
 
-template <int WM, int WN, int TM, int TN, bool CONV, bool STATS, int NST>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 2 : 1)) void gemm_h2d_kernel(GemmArgs p) {
+// SPEC (round 5, 4-wave tiles only): the block carries 4 MORE waves that do nothing but issue the LDS-DMA requests -- one producer and one
+// consumer per SIMD.  With one wave per SIMD the 7 requests of a K step sit in the same in-order instruction stream as the MFMAs: a request
+// that waits for a slot of the (saturated) vector-memory queue stalls the wave's MFMA issue as well.  tools/feed_probe.hip measures that
+// skeleton (the 128 x 96 tile's request stream + fragment reads + MFMAs, no epilogue, 4000 x 768 x 3072): 54.3 us with the requests between
+// the MFMAs, 47.9 us with producer waves; the request pattern (row-major, padded, K-blocked) and the ring depth (3 .. 8) change nothing, and
+// neither does moving one operand to plain VGPR loads (LDS-DMA and VGPR loads share ONE L2 -> CU path: 58 B/clk/CU for either or any mix,
+// profiles/r05_feed_probe.txt).  The producers leave after the K loop (through the first barrier of the epilogue); the consumers' MFMA order
+// per accumulator is unchanged, so results are bit-identical to the 4-wave tile's.  MEASURED IN THE MODEL: slower (see launch_gemm_h2d), so
+// cfg 422 / 423 are opt-in.
+template <int WM, int WN, int TM, int TN, bool CONV, bool STATS, int NST, bool SPEC = false>
+__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), ((WM * WN > 4 || SPEC) ? 2 : 1)) void gemm_h2d_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
+    static_assert(!SPEC || (NW == 4 && !STATS), "producer waves: 4-wave tiles without GroupNorm statistics");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int BKE = 32, ROWB = 128, CPR = 8, RPP = 8;
     constexpr int A_PC = BM / RPP / NW, B_PC = BN / RPP / NW, PER = A_PC + B_PC;
@@ -45,7 +55,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 2 : 1)) void gemm_h2d_
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = SPEC && wave_all >= NW;          // waves NW .. 2 NW - 1: DMA only
+    const int wave = SPEC ? (wave_all & (NW - 1)) : wave_all;      // a producer issues the pieces of the consumer with the same index
     const int wm = wave / WN, wn = wave % WN;
 
     const int nbn = (p.N + BN - 1) / BN;
@@ -194,16 +206,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 2 : 1)) void gemm_h2d_
     for (int i = 0; i < TM; ++i) { ah[1][i] = f16x8{}; al[1][i] = f16x8{}; }     // "half 1 of slice kt0-1": zeros, the loop has no first-step branch
 #pragma unroll
     for (int j = 0; j < TN; ++j) { bh[1][j] = f16x8{}; bl[1][j] = f16x8{}; }
+    if (!SPEC || producer) {
 #pragma unroll
-    for (int i = 0; i < NST - 1; ++i) issue(kt0 + i, i, kt0 + i < nk);
+        for (int i = 0; i < NST - 1; ++i) issue(kt0 + i, i, kt0 + i < nk);
+    }
     int rd = 0, wr = NST - 1;
     __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): no scalar load pending at the loop head, so the waits on the fragment reads inside can be counted
     for (int kt = kt0; kt < nk; ++kt) {
-        d_wait_vm<(NST - 2) * PER>();                      // slice kt landed (this wave's share); NST - 2 younger ones stay in flight
+        if (!SPEC || producer) d_wait_vm<(NST - 2) * PER>();   // slice kt landed (this wave's share); NST - 2 younger ones stay in flight
         __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's reads of slice kt-1 are complete (its slot is requested below)
         d_barrier();                                       // ... everybody's share; everybody is done with the slot of slice kt-1
         const int sbase = lds0 + rd * STAGE;
         rd = rd + 1 == NST ? 0 : rd + 1;
+        if (SPEC) {
+            if (producer) {
+                issue(kt + NST - 1, wr, kt + NST - 1 < nk);
+            } else {      // the 4-wave schedule without the requests
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldfrag(sbase, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 1); mma(1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldfrag(sbase, 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 1); mma(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wr = wr + 1 == NST ? 0 : wr + 1;
+            continue;
+        }
         // every batch of fragment reads is followed by >= 2 TM TN independent MFMAs before the first MFMA that needs it (hipcc
         // waits with lgkmcnt(0) there: a batch issued later than the one needed would be waited for as well)
         __builtin_amdgcn_sched_barrier(0);
@@ -221,6 +256,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 2 : 1)) void gemm_h2d_
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 1); mma(0, 2);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SPEC && producer) {      // every request (the dead ones past the K range too) has landed; leave through the epilogue's first barrier
+        d_wait_vm<0>();
+        __syncthreads();
+        return;
     }
     mma(1, 0); mma(1, 1); mma(1, 2);
     d_wait_vm<0>();
@@ -243,6 +283,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 2 : 1)) void gemm_h2d_
 }
 
 template <int WM, int WN, int TM, int TN, bool CONV, int NST>
+static int launch_h2d_spec(const GemmArgs& a, hipStream_t s) {      // producer / consumer build: plain (no statistics, unsplit) launches only
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+    size_t lds = (size_t)NST * (BM + BN) * 128;
+    if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);
+    static DevOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST, true>), dim3(grid), dim3(128 * WM * WN), lds, s, a);
+    return 0;
+}
+
+template <int WM, int WN, int TM, int TN, bool CONV, int NST>
 static int launch_h2d_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
@@ -261,7 +314,7 @@ static int launch_h2d_cfg(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool gemm_h2d_has_cfg(int cfg) { return cfg == 322 || cfg == 323 || cfg == 331 || cfg == 332 || cfg == 346; }
+bool gemm_h2d_has_cfg(int cfg) { return cfg == 322 || cfg == 323 || cfg == 331 || cfg == 332 || cfg == 346 || cfg == 422 || cfg == 423; }
 
 // what the descriptor addressing covers (everything else stays on gemm_h2_kernel)
 bool gemm_h2d_supported(const GemmArgs& a, int cfg) {
@@ -285,6 +338,19 @@ bool gemm_h2d_supported(const GemmArgs& a, int cfg) {
 int launch_gemm_h2d(const GemmArgs& a, int cfg, bool conv, hipStream_t s) {
     UNI_REQUIRE(gemm_h2d_supported(a, cfg), "gemm(h2, deep): cfg %d does not cover this problem (K %% 32, Cin %% 32, 3x3 taps at most, staged epilogue)", cfg);
 #define GOD(WM, WN, TM, TN, NST) return conv ? launch_h2d_cfg<WM, WN, TM, TN, true, NST>(a, s) : launch_h2d_cfg<WM, WN, TM, TN, false, NST>(a, s)
+    // 422 / 423 = 322 / 323 with producer waves (SPEC); launches they do not cover (GroupNorm statistics, K ranges) take the 4-wave build.
+    // NOT the launcher's choice: in the model the producer build is SLOWER (stage-2 pwconv2 of one frame 76.9 -> 88.7 us, 9.74 -> 9.90 ms per
+    // frame, same box) although the skeleton probe gains 12 % -- with real (random) operands, the epilogue and 8 waves at every barrier the
+    // extra waves cost more than the issue stalls they remove.  Kept as a tested configuration (bit-identical) and behind UNI_H2D_SPEC=1.
+    static const bool want_spec = getenv("UNI_H2D_SPEC") != nullptr;
+    const bool plain = !a.stats && a.splitk <= 1;
+    const bool spec = plain && (cfg == 422 || cfg == 423 || (want_spec && a.force_cfg % 1000 == 0 && (cfg == 322 || cfg == 323)));
+    if (cfg == 422) cfg = 322;
+    if (cfg == 423) cfg = 323;
+#define GOS(WM, WN, TM, TN, NST) return conv ? launch_h2d_spec<WM, WN, TM, TN, true, NST>(a, s) : launch_h2d_spec<WM, WN, TM, TN, false, NST>(a, s)
+    if (spec && cfg == 322) { GOS(2, 2, 2, 2, 4); }
+    if (spec && cfg == 323) { GOS(4, 1, 1, 3, 4); }
+#undef GOS
     switch (cfg) {
         case 322: GOD(2, 2, 2, 2, 4);
         case 323: GOD(4, 1, 1, 3, 4);
