@@ -102,6 +102,22 @@ def rccl_probe_child():
     sys.exit(0 if ok else 4)
 
 
+class _StdoutToStderr:
+    """fd-level redirect of stdout to stderr while a C++ library chats (gloo prints "[Gloo] Rank r is connected to ..." on fd 1 when a
+    group forms): the driver reads ONE JSON line from stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def init_dist(rank, local_rank, world, gpu):
     """Control plane = gloo (CPU tensors, always works, every collective has a timeout); data plane (result-row / RLE gathers) = RCCL
     when a child-process probe succeeded ON EVERY RANK, gloo on host copies otherwise -- the first RCCL contact of this code is the
@@ -113,7 +129,9 @@ def init_dist(rank, local_rank, world, gpu):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process device memory needs it on this host driver
     os.environ.setdefault("NCCL_DEBUG", "WARN")
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+    with _StdoutToStderr():
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+        dist.barrier()          # forms the gloo connections (and their chatter) here, not at the first collective of the run
     info = {"control": "gloo", "data": "gloo", "rccl_probe": None, "env": {"NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}
     want = os.environ.get("UNI_BENCH_BACKEND") or ("nccl" if gpu else "gloo")
@@ -146,10 +164,11 @@ def init_dist(rank, local_rank, world, gpu):
     group = None
     if int(flag[0]) and want == "nccl":
         try:
-            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
-            w = torch.ones(1, device="cuda")
-            dist.all_reduce(w, group=group)
-            torch.cuda.synchronize()
+            with _StdoutToStderr():
+                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                w = torch.ones(1, device="cuda")
+                dist.all_reduce(w, group=group)
+                torch.cuda.synchronize()
             info["data"] = "nccl"
         except Exception as e:                       # noqa: BLE001 -- anything RCCL throws here degrades to the gloo gather
             info["rccl_probe"]["msg"] = "new_group(nccl) failed after a good probe: %r" % (e,)

@@ -15,6 +15,8 @@ def _run(*extra):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout          # rank 0 prints ONE json line
+    # ... and NOTHING else on stdout (gloo's "[Gloo] Rank r is connected to ..." chatter is redirected to stderr while the groups form)
+    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, out.stdout
     return json.loads(lines[0])
 
 
