@@ -53,3 +53,30 @@ def test_spec_failures_exit_nonzero(tmp_path, capsys):
     rep = json.loads(capsys.readouterr().out)
     assert rc == 1 and not rep["pass"]
     assert rep["spec"]["missing"] == ["head.beta_0"] and rep["spec"]["shape_mismatch"] == ["bottleneck.0.weight"]
+
+
+def test_images_option_letterboxes_npy_frames(tmp_path, capsys):
+    """--images: HxWx3 uint8 RGB .npy frames go through the PreprocessorX.process restatement (RGB->BGR, resize by r, pad 114) and the
+    init box is scaled by r; --cpu-only without --ref = spec check + finite oracle outputs"""
+    import numpy as np
+    import synth
+    import unicorn_oracle as uo
+    P = synth.synth_state_dict(uo.CONFIGS["unicorn_track_tiny"])
+    ck = str(tmp_path / "c.pth")
+    torch.save({"model": P}, ck)
+    g = np.random.default_rng(0)
+    files = []
+    for i in range(2):
+        f = str(tmp_path / ("f%d.npy" % i))
+        np.save(f, g.integers(0, 256, (240, 427, 3), dtype=np.uint8))
+        files.append(f)
+    vc = _tool()
+    rc = vc.main(["--ckpt", ck, "--exp", "unicorn_track_tiny", "--cpu-only", "--size", "320x512", "--frames", "1", "--images", *files,
+                  "--box", "100,60,220,180", "--threads", "4"])
+    rep = json.loads(capsys.readouterr().out)
+    assert rc == 0 and rep["pass"] and rep["clip"] == "images" and rep["oracle_finite"]
+    args = vc.parse(["--ckpt", ck, "--exp", "unicorn_track_tiny", "--images", *files, "--frames", "1"])
+    frames, box = vc.make_clip(args, 320, 512)
+    r = min(320 / 240, 512 / 427)
+    assert frames[0].shape == (1, 3, 320, 512) and float(frames[0][0, :, int(240 * r) + 1:].min()) == 114.0      # pad rows
+    assert torch.allclose(box, torch.tensor([427 / 4, 240 / 4, 427 / 2, 240 / 2]) * r)
