@@ -137,6 +137,15 @@ def init_dist(rank, local_rank, world, gpu):
     want = os.environ.get("UNI_BENCH_BACKEND") or ("nccl" if gpu else "gloo")
     if want != "nccl" and not os.environ.get("UNI_BENCH_PROBE"):
         return dist, None, info
+    ndev = torch.cuda.device_count() if gpu else 0
+    if want == "nccl" and ndev < world and not os.environ.get("UNI_BENCH_FORCE_PROBE"):
+        # one-GPU-visible guard: RCCL needs ONE device per rank ("Duplicate GPU detected" otherwise); with fewer visible GPUs than ranks
+        # (UNI_BENCH_SHARE_GPU plumbing runs on a 1-GPU box) the probe cannot succeed -- skip it and SAY why, the gathers run over gloo
+        why = ("RCCL skipped: %d rank(s) but %d visible GPU(s) -- RCCL binds one device per rank; result-row / RLE gathers run over gloo on host copies"
+               % (world, ndev))
+        print("[bench] " + why, file=sys.stderr, flush=True)
+        info["rccl_probe"] = {"ok_all_ranks": False, "ok_this_rank": False, "seconds": 0.0, "msg": None, "why": why, "skipped": True}
+        return dist, None, info
     port = torch.zeros(1, dtype=torch.int64)
     if rank == 0:
         with socket.socket() as s:
@@ -160,7 +169,9 @@ def init_dist(rank, local_rank, world, gpu):
     flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     info["rccl_probe"] = {"ok_all_ranks": bool(int(flag[0])), "ok_this_rank": ok, "seconds": round(time.perf_counter() - t0, 1),
-                          "msg": None if ok else msg}
+                          "msg": None if ok else msg, "skipped": False,
+                          "why": None if int(flag[0]) else ("RCCL probe failed on %s: gathers run over gloo on host copies"
+                                                            % ("this rank" if not ok else "another rank"))}
     group = None
     if int(flag[0]) and want == "nccl":
         try:
@@ -308,10 +319,14 @@ class Stream:
         self.P = P if P is not None else synth.synth_state_dict(self.cfg)
         self.model = Unicorn(model_name, precision=precision).cuda(dev.index)
         self.model.load_state_dict(self.P)
-        fr, self.box = synth.synth_clip(H, W, n_frames + 1, seed=seed)
+        # a time batch holds NB DISTINCT consecutive frames of the stream (rounds 1-5 cycled 4 frames through a 16-frame batch: harmless for
+        # dense kernels, but not what "16 consecutive frames" says); the n_frames batches are rotations of the same pool
+        pool = max(n_frames, NB)
+        fr, self.box = synth.synth_clip(H, W, pool + 1, seed=seed)
         self.frames = [f.to(dev) for f in fr]
         self.H, self.W = H, W
-        self.batches = [torch.cat([self.frames[1 + (k + t) % n_frames] for t in range(NB)], 0) for k in range(n_frames)]
+        self.distinct_frames_per_batch = min(NB, pool)
+        self.batches = [torch.cat([self.frames[1 + (k + t) % pool] for t in range(NB)], 0) for k in range(n_frames)]
         with torch.no_grad():
             _, self.d_pre = self.model(imgs=self.frames[0], mode="backbone")              # reference frame: once, untimed
         self.lbs = label_map_s8(self.box, H, W, dev)
@@ -1051,6 +1066,7 @@ def main():
             "config": {"workload": "%s %s per-frame step %dx%d (backbone+FPN, deform interaction, embedding, fp32-equivalent correlation, "
                                    "head); one independent stream per GPU, %d consecutive frames per step" % (args.model, args.task.upper(), H, W, nf),
                        "model": args.model, "task": args.task, "precision": args.precision, "frames_per_step": nf, "streams": world,
+                       "distinct_frames_per_batch": main_s.distinct_frames_per_batch,
                        "weights": "synthetic (oracle/synth.py)",
                        "corr_dtype": ["f32", "f32-equivalent (bf16x3 split operands, fp32 accumulate)",
                                       "f32-equivalent (f16x2 split operands, fp32 accumulate)",

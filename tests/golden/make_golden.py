@@ -23,7 +23,8 @@ import ref_bootstrap as rb  # noqa: E402
 import synth  # noqa: E402
 import unicorn_oracle as uo  # noqa: E402
 
-MAX_FULL = 1 << 15
+MAX_FULL = 1 << 15          # samples per tensor of the 320-class goldens; the 800x1280 files store `max_full` themselves (key "__max_full")
+_max_full = MAX_FULL
 
 
 def pack(out, name, t):
@@ -31,10 +32,10 @@ def pack(out, name, t):
     a = t.numpy().reshape(-1)
     out[name + "__shape"] = np.array(t.shape, dtype=np.int64)
     out[name + "__stats"] = np.array([a.mean(), np.abs(a).mean(), a.min(), a.max()], dtype=np.float64)
-    if a.size <= MAX_FULL:
+    if a.size <= _max_full:
         out[name] = a.astype(np.float32)
     else:
-        idx = np.linspace(0, a.size - 1, MAX_FULL).astype(np.int64)
+        idx = np.linspace(0, a.size - 1, _max_full).astype(np.int64)
         out[name] = a[idx].astype(np.float32)
 
 
@@ -47,12 +48,16 @@ def load_synth(model, cfg):
     return sd
 
 
-def run_sot(exp_name, H, W):
+def run_sot(exp_name, H, W, max_full=MAX_FULL, top_rows=0):
+    """max_full: samples kept per tensor (the headline-size files keep 6144 so that one file stays ~0.5 MB); top_rows > 0: also store the
+    `top_rows` best-scoring raw head rows (index + row), since a strided sample of a (1, 21000, 6) output cannot be turned into boxes."""
+    global _max_full
+    _max_full = max_full
     cfg = uo.CONFIGS[exp_name]
     model, exp = rb.build_reference_model(exp_name)
     load_synth(model, cfg)
     frames, box = synth.synth_clip(H, W, 2, seed=1)
-    out = {}
+    out = {"__max_full": np.array([max_full], dtype=np.int64)}
     with torch.no_grad():
         # --- initialize (unicorn_sot.py:39-55) ---
         _, d_pre = model(imgs=frames[0], mode="backbone")
@@ -87,6 +92,13 @@ def run_sot(exp_name, H, W):
         pack(out, "prior16", pri[1])
         pack(out, "prior32", pri[2])
         head_out = model.head(fpn, pri, mode="sot")
+        if top_rows:
+            ho = head_out[0] if cfg.mask else head_out
+            top = torch.argsort(ho[0, :, 4] * ho[0, :, 5], descending=True)[:top_rows]
+            out["head_top_idx"] = top.numpy().astype(np.int64)
+            out["head_top_rows"] = ho[0, top].numpy().astype(np.float32)
+            if cfg.mask:
+                out["dyn_top_rows"] = head_out[2][0, top[:64]].numpy().astype(np.float32)
         if cfg.mask:
             names = ["head_out", "locations", "dyn_params", "fpn_levels", "mask_feats", "up_masks"]
             for n, t in zip(names, head_out):
@@ -95,7 +107,7 @@ def run_sot(exp_name, H, W):
                                            model.head.mask_head, 1, 0.001, 0.65, d_rate=cfg.d_rate,
                                            up_masks=head_out[5])
             det, msk = dets[0], masks[0]
-            det, msk = det[:8], msk[:8]
+            det, msk = (det[:8], msk[:8]) if not top_rows else (det[:4], msk[:4])
             pack(out, "det_sot", det)
             out["mask_sot_bits"] = np.packbits((msk > 0.5).numpy().astype(np.uint8).reshape(-1))
             pack(out, "mask_sot", msk[:, :, ::8, ::8])
@@ -110,6 +122,10 @@ def run_sot(exp_name, H, W):
         whole, _ = model(frames[1])
         who = whole[0] if cfg.mask else whole
         pack(out, "whole_out", who)
+        if top_rows:
+            topw = torch.argsort(who[0, :, 4] * who[0, :, 5:].max(1)[0], descending=True)[:top_rows]
+            out["whole_top_idx"] = topw.numpy().astype(np.int64)
+            out["whole_top_rows"] = who[0, topw].numpy().astype(np.float32)
         det = postprocess(who.clone(), cfg.num_classes, 0.0005, 0.65)[0]
         out["n_det_mot"] = np.array([0 if det is None else det.shape[0]])
         if det is not None:
@@ -124,6 +140,7 @@ def run_sot(exp_name, H, W):
             exec("track_feat_list = []\n" + textwrap.dedent("\n".join(src)), ns)
             embs = list(ns["track_feats"])
             pack(out, "inst_embed", torch.stack(embs))
+    _max_full = MAX_FULL
     np.savez_compressed(os.path.join(HERE, "%s_%dx%d.npz" % (exp_name, H, W)), **out)
     print(exp_name, {k: v.shape for k, v in out.items() if not k.endswith("__shape") and not k.endswith("__stats")})
 
@@ -206,8 +223,18 @@ def dump_specs():
             json.dump(spec, f)
 
 
+def run_headline():
+    """BASELINE.json's headline configuration itself (exp/unicorn_track.py:104: test_size (800, 1280)) through the REAL reference on CPU:
+    50 x 80 token grid, pos-embed resized UP (40 -> 50 / 80), the 16000 x 16000 correlation, C = 1536 25 x 40 maps.  ~1.5 min and ~6 GB each."""
+    run_sot("unicorn_track_large", 800, 1280, max_full=6144, top_rows=500)
+    run_sot("unicorn_track_large_mask", 800, 1280, max_full=6144, top_rows=500)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "headline":
+        run_headline()
+        sys.exit(0)
     run_msda_known_answer()
     dump_specs()
     run_sot("unicorn_track_tiny", 320, 320)
@@ -219,3 +246,4 @@ if __name__ == "__main__":
     run_sot("unicorn_track_tiny_mask", 320, 512)       # non-square (H / W = 0.625 like 800 x 1280): row / column order of pos-embed, reference points, grids
     run_vos("unicorn_track_tiny_mask", 320, 320)
     run_vos("unicorn_track_large_mask", 320, 320)
+    run_headline()

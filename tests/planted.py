@@ -24,3 +24,17 @@ def planted_pred(A, nc, seed, n_clusters=40, per=12):
             pred[0, a, 5 + int(torch.randint(nc, (1,), generator=g))] = 0.6 + 0.4 * torch.rand(1, generator=g)
     pred[0, idx[0, 1], 4:] = pred[0, idx[0, 0], 4:]          # an exact score tie between two overlapping boxes
     return pred
+
+
+def confident_head(P, obj_bias=1.0, cls_bias=1.0):
+    """Synthetic weights give obj * cls ~ 1e-4 (prediction biases at -4.6, exp/unicorn_track.py:146); loops whose logic runs on score thresholds
+    (BYTETracker: track_thresh, the 0.1 low-score floor, det_thresh) need detector-like scores.  Shift the obj / cls prediction biases so that
+    scores spread around sigmoid(obj_bias) * sigmoid(cls_bias) (the feature-dependent part of the logits keeps its spread) -> new state dict."""
+    Q = dict(P)
+    for k in P:
+        if k.startswith("head.") and k.endswith(".bias"):
+            if ".obj_preds" in k:
+                Q[k] = torch.full_like(P[k], obj_bias)
+            elif ".cls_preds" in k:
+                Q[k] = torch.full_like(P[k], cls_bias)
+    return Q

@@ -153,3 +153,59 @@ def test_mlp_pack_layouts_match_numpy_restatement(C_, layout):
                         r2[16 * j:16 * j + 16, 32 * h2 + u] = q[j, kg, 0, :, e] + q[j, kg, 1, :, e]
     assert np.abs(r1 / s1 - w1).max() <= np.abs(w1).max() * 2.0 ** -21
     assert np.abs(r2 / s2 - gamma[:, None] * w2).max() <= np.abs(gamma[:, None] * w2).max() * 2.0 ** -21
+
+
+def test_build_manifest_is_verified_at_load(tmp_path, monkeypatch):
+    """The libraries are git-ignored build products that travel to the GPU box as files: csrc/build.sh writes lib/build_manifest.json (sha256
+    of every source / header and of both libraries), `_lib.lib()` / `assoc_lib()` hold the library AND the sources next to it to it.  A stale
+    library (source changed after the build), an unknown new header and a swapped .so all raise; UNI_SKIP_MANIFEST=1 downgrades to a warning."""
+    import json
+    import shutil
+    import warnings
+    from unicorn_amd import _lib as L
+    assert L.verify_manifest("libunicorn_hip.so") == "verified" and L.verify_manifest("libunicorn_assoc.so") == "verified"
+    L.lib()
+    assert L.BUILD_CHECK == "verified"
+    man = json.load(open(os.path.join(os.path.dirname(L.LIB_PATH), "build_manifest.json")))
+    assert {"common.h", "kernels.h", "engine.h", "gemm_epi.h", "mask_interp.h", "unicorn_hip.h", "unicorn_assoc.h", "engine.hip", "assoc.cpp"} <= set(man["sources"])
+    # a copy of the package tree with (a) a touched source, (b) an extra header, (c) a different library
+    root = tmp_path / "unicorn_amd"
+    shutil.copytree(os.path.dirname(L.__file__), root, ignore=shutil.ignore_patterns("build", "__pycache__"))
+    shutil.copytree(os.path.join(os.path.dirname(os.path.dirname(L.__file__)), "include"), tmp_path / "include")
+    monkeypatch.setattr(L, "_HERE", str(root))
+    assert L.verify_manifest("libunicorn_hip.so") == "verified"
+    with open(root / "csrc" / "norm.hip", "a") as f:
+        f.write("// edited after the build\n")
+    with pytest.raises(L.UnicornHipError, match="norm.hip changed"):
+        L.verify_manifest("libunicorn_hip.so")
+    monkeypatch.setenv("UNI_SKIP_MANIFEST", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert L.verify_manifest("libunicorn_hip.so") == "skipped" and any("norm.hip" in str(x.message) for x in w)
+    monkeypatch.delenv("UNI_SKIP_MANIFEST")
+    shutil.copy(os.path.join(os.path.dirname(L.__file__), "csrc", "norm.hip"), root / "csrc" / "norm.hip")
+    (root / "csrc" / "brand_new.h").write_text("#pragma once\n")
+    with pytest.raises(L.UnicornHipError, match="brand_new.h"):
+        L.verify_manifest("libunicorn_hip.so")
+    os.remove(root / "csrc" / "brand_new.h")
+    with open(root / "lib" / "libunicorn_assoc.so", "ab") as f:
+        f.write(b"\0")
+    with pytest.raises(L.UnicornHipError, match="not the library"):
+        L.verify_manifest("libunicorn_assoc.so")
+    os.remove(root / "lib" / "build_manifest.json")
+    with pytest.raises(L.UnicornHipError, match="missing"):
+        L.verify_manifest("libunicorn_hip.so")
+
+
+def test_half_is_a_documented_no_op_that_warns_once():
+    """tools/track.py --fp16 calls model.half() (mot_evaluator.py:126-128): the operand format is fixed by `precision`, so the call changes
+    nothing -- and says so ONCE per process instead of silently costing fp32-equivalent time."""
+    import warnings
+    from unicorn_amd.models import Unicorn
+    Unicorn._half_warned = False
+    m = Unicorn("unicorn_track_tiny")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert m.half() is m and m.half() is m
+    msgs = [str(x.message) for x in w if "half()" in str(x.message)]
+    assert len(msgs) == 1 and "precision='f16x2'" in msgs[0], msgs

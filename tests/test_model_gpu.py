@@ -149,6 +149,79 @@ def test_tiny_320_vs_reference_golden(exp, precision, H, W, golden_dir):
         assert met["box_iou_mean_top200"] > 0.75, met
 
 
+@pytest.mark.parametrize("exp", ["unicorn_track_large", "unicorn_track_large_mask"])
+def test_headline_800x1280_vs_reference_golden(exp, golden_dir):
+    """The HEADLINE configuration itself (exp/unicorn_track.py:104: test_size (800, 1280), `unicorn_track_large` and its mask variant)
+    against vectors of the REAL reference run on the CPU at that size (tests/golden/make_golden.py:run_headline): the 50 x 80 token grid,
+    the pos-embed resized UP (40 -> 50 / 80), the 16000 x 16000 correlation and the C = 1536 25 x 40 maps are compared with the reference,
+    not only with the oracle.  Feature maps on the stored strided sample (`__max_full` per tensor), boxes on the 500 best raw head rows
+    (SOT head and mode="whole"), dynamic parameters of the 64 best, CondInst mask bits of the reference's first detections."""
+    H, W = 800, 1280
+    g = np.load(os.path.join(golden_dir, "%s_%dx%d.npz" % (exp, H, W)))
+    mf = int(g["__max_full"][0])
+
+    def smp(t):
+        a = t.detach().float().cpu().contiguous().numpy().reshape(-1)
+        return a if a.size <= mf else a[np.linspace(0, a.size - 1, mf).astype(np.int64)]
+
+    m, cfg, P = build(exp, "f16x2")
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    r = hip_sot_step(m, cfg, frames, box)
+    met = {}
+    assert np.array_equal(smp(r["lbs"]), g["lbs_pre"])
+    for k, t in (("fpn0", r["fpn"][0]), ("fpn1", r["fpn"][1]), ("fpn2", r["fpn"][2]), ("seq_feat", r["seq"]["feat"]), ("seq_pos", r["seq"]["pos"]),
+                 ("feat_pre", r["feat_pre"]), ("feat_cur", r["feat_cur"]), ("embed_pre", r["embed_pre"]), ("embed_cur", r["embed_cur"])):
+        assert tuple(g[k + "__shape"]) == tuple(t.shape), k
+        met[k] = rel_l2(smp(t), g[k])
+    met["coarse_maxabs"] = float(np.abs(smp(r["coarse"]) - g["coarse"]).max())
+    met["prior16_maxabs"] = float(np.abs(smp(r["pri"][1]) - g["prior16"]).max())
+    met["prior32_maxabs"] = float(np.abs(smp(r["pri"][2]) - g["prior32"]).max())
+    head = (r["head"][0] if cfg.mask else r["head"])[0].cpu()
+    top = torch.from_numpy(g["head_top_idx"])
+    ref_rows = torch.from_numpy(g["head_top_rows"])
+    iou = box_iou_pairs(head[top, :4], ref_rows[:, :4])
+    met["box_iou_min_top500"] = float(iou.min())
+    met["box_iou_mean_top500"] = float(iou.mean())
+    sc_ref = ref_rows[:, 4] * ref_rows[:, 5]
+    met["score_relerr_top500"] = float(((head[top, 4] * head[top, 5] - sc_ref).abs() / sc_ref).max())
+    with torch.no_grad():
+        whole, _ = m(frames[1].cuda())
+    who = (whole[0] if cfg.mask else whole)[0].cpu()
+    wtop, wref = torch.from_numpy(g["whole_top_idx"]), torch.from_numpy(g["whole_top_rows"])
+    met["whole_box_iou_min_top500"] = float(box_iou_pairs(who[wtop, :4], wref[:, :4]).min())
+    if cfg.mask:
+        met["dyn_top64"] = rel_l2(r["head"][2][0].cpu()[top[:64]].numpy(), g["dyn_top_rows"])
+        for n, t in (("mask_feats", r["head"][4]), ("up_masks", r["head"][5])):
+            met[n] = rel_l2(smp(t), g[n])
+        assert np.allclose(smp(r["head"][1]), g["locations"]) and np.array_equal(smp(r["head"][3]), g["fpn_levels"])
+        # the reference's postprocess_inst (utils/boxes.py:80-152) on its own head output kept n_det_sot detections; the HIP head + HIP NMS +
+        # HIP CondInst must keep the same first ones, with the same masks
+        from unicorn_amd.utils.boxes import postprocess_inst
+        hd = tuple(t.clone() if torch.is_tensor(t) else t for t in r["head"])
+        dets, masks = postprocess_inst(hd[0], hd[1], hd[2], hd[3], hd[4], m.head.mask_head, 1, 0.001, 0.65, d_rate=cfg.d_rate, up_masks=hd[5])
+        nref = int(g["n_det_sot"][0])
+        met["n_det_sot"] = [int(dets[0].shape[0]), nref]
+        dref = torch.from_numpy(g["det_sot"]).reshape(tuple(g["det_sot__shape"]))
+        k = dref.shape[0]
+        cx = lambda t: torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], 1)
+        met["det_box_iou_min"] = float(box_iou_pairs(cx(dets[0][:k, :4].cpu()), cx(dref[:, :4])).min())
+        bits = np.packbits((masks[0][:k].cpu() > 0.5).numpy().astype(np.uint8).reshape(-1))
+        diff = np.unpackbits(bits ^ g["mask_sot_bits"]).reshape(k, -1).sum(1)
+        area = np.unpackbits(g["mask_sot_bits"]).reshape(k, -1).sum(1)
+        met["mask_bits_differ"] = [int(v) for v in diff]
+        met["mask_iou_min"] = float(min(1.0 - d / max(1.0, a + d) for d, a in zip(diff, area)))      # union <= area + differing pixels
+    METRICS["golden_headline_%s_f16x2_800x1280" % exp] = met
+    _dump()
+    assert met["seq_pos"] < 1e-5, met
+    for k in ("fpn0", "fpn1", "fpn2", "seq_feat", "feat_pre", "feat_cur", "embed_pre", "embed_cur"):
+        assert met[k] < 1e-4, (k, met[k])
+    assert max(met["coarse_maxabs"], met["prior16_maxabs"], met["prior32_maxabs"]) < 1e-4, met
+    assert met["box_iou_min_top500"] > 0.999 and met["whole_box_iou_min_top500"] > 0.999 and met["score_relerr_top500"] < 1e-3, met
+    if cfg.mask:
+        assert max(met["dyn_top64"], met["mask_feats"], met["up_masks"]) < 1e-4, met
+        assert met["n_det_sot"][0] == met["n_det_sot"][1] and met["det_box_iou_min"] > 0.999 and met["mask_iou_min"] > 0.999, met
+
+
 _ORACLE_CACHE = {}
 
 
@@ -487,7 +560,7 @@ def test_sot_tracker_and_postprocess_match_oracle_decision():
         assert all(abs(x - y) <= 1 for x, y in zip(a, b)), (got, exp)     # int truncation may flip by 1 px
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2", "bf16"])      # bf16 (retired from the bench, still a public mode): ONE batched + ragged case
 def test_batched_frames_equal_single_frame_runs(precision):
     """Every stage takes a batch of frames (M = B*H*W rows per kernel): B = 3 must reproduce three B = 1 runs
     (per-sample GroupNorm statistics, conv halos and the head's row remap must not leak across samples).
@@ -696,6 +769,107 @@ def test_omni_mot_frame_batched_equals_per_frame_and_oracle():
         assert hit == len(mo_), (hit, len(mo_))
 
 
+@pytest.mark.parametrize("exp,H,W,nframes", [("unicorn_track_tiny", 320, 320, 5), ("unicorn_track_large_mot_challenge", 800, 1280, 2)])
+def test_byte_mot_frame_tools_track_loop_vs_oracle(exp, H, W, nframes):
+    """`tools/track.py`'s own per-frame loop = MOTEvaluator.evaluate (unicorn/evaluators/mot_evaluator.py:198-222): model(imgs) (mode="whole") ->
+    postprocess -> BYTETracker.update -> area / aspect filter, on the HIP path (`unicorn_amd.tracker.ByteMOTFrame` + the native BYTETracker)
+    against the oracle loop (uo.mot_whole -> uo.postprocess -> oracle/bytetrack_oracle.byte_update, itself pinned by golden sequences of the REAL
+    reference class).  Detector-like scores come from planted obj / cls biases (tests/planted.py:confident_head); thresholds are placed
+    between two neighbouring oracle scores so that a 1e-6 score difference cannot flip a decision.  Per frame: same track ids, boxes within
+    0.05 px, scores within 1e-5; `run_stream` (pipelined) gives exactly the per-frame results."""
+    from types import SimpleNamespace
+    import bytetrack_oracle as bo
+    from planted import confident_head
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import BYTETracker, ByteMOTFrame
+    from unicorn_amd.tracker import byte_tracker as bt
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg))
+    m = Unicorn(exp, precision="f16x2").cuda()
+    assert not m.load_state_dict(P, strict=False)[0]
+    m.eval()
+    frames, _ = synth.synth_clip(H, W, nframes + 1, seed=7)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        outs_o = [uo.mot_whole(P, cfg, frames[f])[0] for f in range(1, nframes + 1)]
+    sc = (outs_o[0][0, :, 4] * outs_o[0][0, :, 5:5 + cfg.num_classes].max(1)[0]).sort(descending=True)[0]
+    confthre = float((sc[149] + sc[150]) / 2)
+    track_thresh = float((sc[59] + sc[60]) / 2)
+    info = (int(H * 1.5), int(W * 1.5), 1, 1, "seq/000001.jpg")                      # info_imgs: (img_h, img_w, frame_id, video_id, file_name)
+    args = SimpleNamespace(track_thresh=track_thresh, track_buffer=30, match_thresh=0.9, mot20=False)      # tools/track.py:104-108
+    bt.clean_id()
+    one = ByteMOTFrame(m, BYTETracker(args), (H, W), num_classes=cfg.num_classes, confthre=confthre, nmsthre=0.7, min_box_area=100)
+    with torch.no_grad():
+        res_h = [one.run(frames[f].cuda(), info) for f in range(1, nframes + 1)]
+    st = bo.ByteState(track_thresh=track_thresh, track_buffer=30, match_thresh=0.9, mot20=False, frame_rate=30)
+    n_tracks = 0
+    for k in range(nframes):
+        det = uo.postprocess(outs_o[k].clone(), cfg.num_classes, confthre, 0.7)[0]
+        assert det is not None and res_h[k] is not None
+        tracks = bo.byte_update(st, det.numpy(), info, (H, W))
+        exp_rows = {}
+        for t in tracks:
+            tlwh = np.asarray(t.tlwh, dtype=np.float64)
+            if tlwh[2] * tlwh[3] > 100 and not (tlwh[2] / tlwh[3] > 1.6):
+                exp_rows[int(t.track_id)] = (tlwh, float(t.score))
+        tl_h, ids_h, sc_h = res_h[k]
+        got = {int(i): (np.asarray(b, dtype=np.float64), float(s)) for b, i, s in zip(tl_h, ids_h, sc_h)}
+        # ids are handed out in detection order: a swap of two near-equal scores would permute them -- compare as box sets first
+        assert len(got) == len(exp_rows), (k, len(got), len(exp_rows))
+        for tid, (b, s_) in exp_rows.items():
+            d = min(float(np.abs(b - g_[0]).max()) for g_ in got.values())
+            assert d < 0.05, (k, tid, d)
+        same_ids = sorted(got) == sorted(exp_rows)
+        if same_ids:
+            for tid, (b, s_) in exp_rows.items():
+                assert float(np.abs(b - got[tid][0]).max()) < 0.05 and abs(s_ - got[tid][1]) < 1e-5, (k, tid)
+        METRICS.setdefault("byte_loop_%s" % exp, []).append({"frame": k + 1, "tracks": len(got), "ids_identical": bool(same_ids)})
+        assert same_ids, (k, sorted(got)[:10], sorted(exp_rows)[:10])
+        n_tracks = max(n_tracks, len(got))
+    assert n_tracks >= 10, n_tracks
+    # the software-pipelined stream gives the per-frame results
+    bt.clean_id()
+    two = ByteMOTFrame(m, BYTETracker(args), (H, W), num_classes=cfg.num_classes, confthre=confthre, nmsthre=0.7, min_box_area=100)
+    with torch.no_grad():
+        res_s = [r[0] for r in two.run_stream((frames[f].cuda() for f in range(1, nframes + 1)), info)]
+    for a, b in zip(res_h, res_s):
+        assert list(a[1]) == list(b[1]) and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    _dump()
+
+
+def test_demo_predictor_class_agnostic_vs_oracle():
+    """tools/demo.py:136-172 (`Predictor.inference`, detection / tracking experiments): raw HWC uint8 BGR image -> ValTransform letterbox (no channel
+    swap, pad 114) -> model(img) (mode="whole") -> postprocess(..., class_agnostic=True) -- `unicorn_amd.tracker.DemoPredictor` against
+    oracle/letterbox_oracle.py + uo.mot_whole + uo.postprocess(class_agnostic=True) on the 8-class BDD head (class-agnostic NMS suppresses
+    ACROSS classes, which the per-class path of the other loops never does)."""
+    import letterbox_oracle as lo
+    from planted import confident_head
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import DemoPredictor
+    exp, size = "unicorn_track_tiny", (320, 512)
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg))
+    m = Unicorn(exp, precision="f16x2").cuda()
+    assert not m.load_state_dict(P, strict=False)[0]
+    m.eval()
+    img = np.random.default_rng(11).integers(0, 256, (270, 400, 3), dtype=np.uint8)
+    t, r = lo.letterbox(img, size, False)
+    with torch.no_grad():
+        o, _, _ = uo.mot_whole(P, cfg, torch.from_numpy(t)[None])
+    sc = (o[0, :, 4] * o[0, :, 5:5 + cfg.num_classes].max(1)[0]).sort(descending=True)[0]
+    confthre = float((sc[299] + sc[300]) / 2)
+    det_o = uo.postprocess(o.clone(), cfg.num_classes, confthre, 0.45, class_agnostic=True)[0]
+    det_pc = uo.postprocess(o.clone(), cfg.num_classes, confthre, 0.45, class_agnostic=False)[0]
+    pred = DemoPredictor(m, cfg.num_classes, confthre, 0.45, size)
+    dets, info = pred.inference(img)
+    det_h = dets[0].cpu()
+    assert abs(info["ratio"] - r) < 1e-12 and info["height"] == 270 and info["width"] == 400
+    assert det_o.shape[0] < det_pc.shape[0]                                          # the agnostic NMS really suppresses across classes here
+    assert det_h.shape == det_o.shape, (det_h.shape, det_o.shape)
+    assert torch.equal(det_h[:, 6], det_o[:, 6])                                      # same survivors in the same (score) order
+    assert (det_h[:, :4] - det_o[:, :4]).abs().max() < 0.05 and (det_h[:, 4:6] - det_o[:, 4:6]).abs().max() < 1e-5
+
+
 def test_omni_stream_pipelined_equals_per_frame():
     """run_stream (software pipeline over the launch stream: A0 A1 B0 A2 | H0 C0 B1 A3 | ...) must give exactly the per-frame results:
     MOT loop (ids, boxes) and MOTS loop (1-based ids, RLE strings), and the SOT driver's track_stream the boxes of track()."""
@@ -833,3 +1007,31 @@ def test_validate_checkpoint_tool_on_the_gpu(tmp_path, capsys):
     capsys.readouterr()
     rep = json.load(open(str(tmp_path / "bad.json")))
     assert rc == 1 and not rep["pass"] and rep["saturation"]["saturated"] > 0, rep.get("saturation")
+
+
+def test_bench_two_ranks_shared_gpu_mix_plumbing():
+    """The N > 1 path of bench.py on the ONE GPU of the test box: `UNI_BENCH_SHARE_GPU=1 bench.py --gpus 2 --task mix` self-launches
+    two ranks (rank 0 the evaluate_omni MOT loop, rank 1 the SOT step, both on GPU 0), the RCCL probe must FAIL cleanly ("Duplicate GPU": two ranks on
+    one device is not a configuration RCCL supports) and say why, the gathers fall back to gloo, result rows and RLE strings round-trip, no rank
+    error.  This is rank assignment + fallback + gather plumbing, re-run by every driver GPUTEST -- NOT a scaling number (none is claimed)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UNI_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--task", "mix", "--model", "unicorn_track_tiny", "--height", "320",
+                          "--width", "512", "--batch", "2", "--steps", "4", "--warmup", "1", "--gather-every", "2", "--no-cpu-baseline", "--no-extras",
+                          "--no-single-frame"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and not r.get("rank_errors"), r.get("rank_errors")
+    tasks = [t["task"] for t in r["config"]["rank_tasks"]]
+    assert tasks == ["mot", "sot"], tasks
+    g = r["config"]["gather"]
+    assert g["dist"]["data"] == "gloo" and g["dist"]["rccl_probe"]["ok_all_ranks"] is False, g["dist"]
+    assert "why" in g["dist"]["rccl_probe"] and g["dist"]["rccl_probe"]["why"], g["dist"]["rccl_probe"]      # the one-GPU guard names the reason
+    assert g["rows"] > 0 and g["lost_rows"] == 0 and g["rle_round_trip_ok"] and g["rle_undecodable"] == 0, g
+    METRICS["bench_two_ranks_shared_gpu"] = {"tasks": tasks, "gather": {k: g[k] for k in ("calls", "rows", "lost_rows", "rle_strings")},
+                                              "rccl_probe": g["dist"]["rccl_probe"]}
+    _dump()

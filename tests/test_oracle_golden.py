@@ -13,20 +13,26 @@ import unicorn_oracle as uo
 MAX_FULL = 1 << 15
 
 
-def sample(t):
+def sample(t, max_full=MAX_FULL):
     a = t.detach().float().contiguous().numpy().reshape(-1)
-    if a.size <= MAX_FULL:
+    if a.size <= max_full:
         return a
-    return a[np.linspace(0, a.size - 1, MAX_FULL).astype(np.int64)]
+    return a[np.linspace(0, a.size - 1, max_full).astype(np.int64)]
 
 
-def check(g, name, t, rtol=1e-4, atol=1e-4):
+# Oracle and reference are both fp32 torch-CPU programs: the backbone / FPN maps come out BIT-IDENTICAL, everything behind the interaction
+# within 4e-6 of the largest element (measured over all golden cases, round 6: worst `coarse` 3.5e-6, `dyn_params` 2.4e-6).  The bar is
+# 1e-5 x scale -- tight enough to catch a wrong eps or a dropped bias that the 2e-4 of rounds 1-5 could hide behind a large-magnitude map.
+TOL = 1e-5
+
+
+def check(g, name, t, tol=TOL):
     assert tuple(g[name + "__shape"]) == tuple(t.shape), name
     ref = g[name]
-    got = sample(t)
+    got = sample(t, int(g["__max_full"][0]) if "__max_full" in g.files else MAX_FULL)
     scale = max(1.0, float(np.abs(ref).max()))
     err = np.abs(got - ref).max()
-    assert err <= atol * scale + rtol * scale, "%s: max err %g (scale %g)" % (name, err, scale)
+    assert err <= tol * scale, "%s: max err %g (scale %g)" % (name, err, scale)
 
 
 @pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_tiny_mask", "unicorn_track_large",
@@ -74,10 +80,10 @@ def test_sot_step_matches_reference(exp, H, W, golden_dir):
         check(g, "feat_cur", r["feat_cur"])
         check(g, "embed_pre", r["embed_pre"])
         check(g, "embed_cur", r["embed_cur"])
-        check(g, "coarse", r["coarse"], atol=1e-5)
+        check(g, "coarse", r["coarse"])
         pri = uo.prior_pyramid(r["coarse"])
-        check(g, "prior16", pri[1], atol=1e-5)
-        check(g, "prior32", pri[2], atol=1e-5)
+        check(g, "prior16", pri[1])
+        check(g, "prior32", pri[2])
         if cfg.mask:
             names = ["head_out", "locations", "dyn_params", "fpn_levels", "mask_feats", "up_masks"]
             for n, t in zip(names, r["head"]):
@@ -90,7 +96,7 @@ def test_sot_step_matches_reference(exp, H, W, golden_dir):
             ref_bits = g["mask_sot_bits"]
             diff = np.unpackbits(bits ^ ref_bits).sum()
             assert diff <= 1e-5 * ref_bits.size * 8, diff
-            check(g, "mask_sot", masks[:8][:, :, ::8, ::8])
+            check(g, "mask_sot", masks[:8][:, :, ::8, ::8], tol=5e-5)      # sigmoid of the dynamic-MLP logits (|logit| up to ~30): 1.4e-5 measured
         else:
             check(g, "head_out", r["head"])
             det = uo.postprocess(r["head"].clone(), 1, 0.001, 0.65)[0]
@@ -105,6 +111,57 @@ def test_sot_step_matches_reference(exp, H, W, golden_dir):
             check(g, "det_mot", det[:64])
             emb = uo.sample_instance_embeddings(r["embed_cur"], det[:16, :4])
             check(g, "inst_embed", emb)
+
+
+@pytest.mark.parametrize("exp", ["unicorn_track_large", "unicorn_track_large_mask"])
+def test_headline_800x1280_matches_reference(exp, golden_dir):
+    """The HEADLINE configuration (exp/unicorn_track.py:104: test_size (800, 1280)) through the REAL reference on the CPU
+    (tests/golden/make_golden.py:run_headline): 50 x 80 token grid, pos-embed resized UP (40 -> 50 / 80), the 16000 x 16000 correlation, the
+    C = 1536 25 x 40 maps -- the oracle that the GPU tests and bench.py's in-run parity lean on at this size is held to the reference AT
+    this size, not only at 320 x 320.  Raw head rows of the 500 best anchors (SOT head and mode="whole") are compared row by row."""
+    torch.set_num_threads(8)
+    H, W = 800, 1280
+    g = np.load(os.path.join(golden_dir, "%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = synth.synth_state_dict(cfg)
+    frames, box = synth.synth_clip(H, W, 2, seed=1)
+    with torch.no_grad():
+        st = uo.sot_init(P, cfg, frames[0], box)
+        check(g, "lbs_pre", st["lbs_pre"])
+        r = uo.sot_step(P, cfg, st, frames[1])
+        for i in range(3):
+            check(g, "fpn%d" % i, r["fpn"][i])
+        for k, t in (("seq_feat", r["seq"]["feat"]), ("seq_pos", r["seq"]["pos"]), ("feat_pre", r["feat_pre"]), ("feat_cur", r["feat_cur"]),
+                     ("embed_pre", r["embed_pre"]), ("embed_cur", r["embed_cur"]), ("coarse", r["coarse"])):
+            check(g, k, t)
+        pri = uo.prior_pyramid(r["coarse"])
+        check(g, "prior16", pri[1])
+        check(g, "prior32", pri[2])
+        head = r["head"][0] if cfg.mask else r["head"]
+        check(g, "head_out", head)
+        top = torch.from_numpy(g["head_top_idx"])
+        ref = torch.from_numpy(g["head_top_rows"])
+        assert torch.equal(torch.argsort(head[0, :, 4] * head[0, :, 5], descending=True)[:50], top[:50])      # same ranking at the top
+        assert (head[0, top] - ref).abs().max() <= TOL * float(ref.abs().max())
+        if cfg.mask:
+            for n, t in zip(["locations", "dyn_params", "fpn_levels", "mask_feats", "up_masks"], r["head"][1:]):
+                check(g, n, t)
+            assert (r["head"][2][0, top[:64]] - torch.from_numpy(g["dyn_top_rows"])).abs().max() <= TOL * float(np.abs(g["dyn_top_rows"]).max())
+            det, masks = uo.postprocess_inst(cfg, tuple(t.clone() for t in r["head"]), 1, 0.001, 0.65)
+            assert det.shape[0] == int(g["n_det_sot"][0])
+            k = int(g["det_sot__shape"][0])
+            check(g, "det_sot", det[:k])
+            bits = np.packbits((masks[:k] > 0.5).numpy().astype(np.uint8).reshape(-1))
+            assert np.unpackbits(bits ^ g["mask_sot_bits"]).sum() <= 1e-5 * g["mask_sot_bits"].size * 8
+        else:
+            det = uo.postprocess(head.clone(), 1, 0.001, 0.65)[0]
+            assert det.shape[0] == int(g["n_det_sot"][0])
+            check(g, "det_sot", det[:64])
+        whole, _, _ = uo.mot_whole(P, cfg, frames[1])
+        who = whole[0] if cfg.mask else whole
+        check(g, "whole_out", who)
+        wtop, wref = torch.from_numpy(g["whole_top_idx"]), torch.from_numpy(g["whole_top_rows"])
+        assert (who[0, wtop] - wref).abs().max() <= TOL * float(wref.abs().max())
 
 
 @pytest.mark.parametrize("exp", ["unicorn_track_tiny_mask", "unicorn_track_large_mask"])
@@ -131,7 +188,7 @@ def test_vos_step_matches_reference(exp, golden_dir):
         bits = np.packbits((mask > 0.5).numpy().astype(np.uint8).reshape(-1))
         diff = np.unpackbits(bits ^ g["mask_bits_%s" % k]).sum()
         assert diff <= 1e-4 * mask.numel(), (k, diff)
-        check(g, "mask_%s" % k, mask[::4, ::4])
+        check(g, "mask_%s" % k, mask[::4, ::4], tol=5e-5)
 
 
 def test_letterbox_oracle_known_answers():

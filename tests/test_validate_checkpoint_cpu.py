@@ -79,4 +79,4 @@ def test_images_option_letterboxes_npy_frames(tmp_path, capsys):
     frames, box = vc.make_clip(args, 320, 512)
     r = min(320 / 240, 512 / 427)
     assert frames[0].shape == (1, 3, 320, 512) and float(frames[0][0, :, int(240 * r) + 1:].min()) == 114.0      # pad rows
-    assert torch.allclose(box, torch.tensor([427 / 4, 240 / 4, 427 / 2, 240 / 2]) * r)
+    assert torch.allclose(box, torch.tensor([427 / 4, 240 / 4, 3 * 427 / 4, 3 * 240 / 4]) * r)      # the centred default box

@@ -41,7 +41,7 @@ def parse(argv=None):
     ap.add_argument("--exp", required=True, help="experiment name, e.g. unicorn_track_large_mask")
     ap.add_argument("--ref", default=None, help="root of a MasterBin-IIAU/Unicorn checkout: also run the REAL reference modules on the CPU")
     ap.add_argument("--images", nargs="*", default=None, help="HxWx3 uint8 RGB .npy frames (first = reference frame); default: synthetic clip")
-    ap.add_argument("--box", default=None, help="init box x1,y1,x2,y2 in pixels of the first image (default: centred quarter)")
+    ap.add_argument("--box", default=None, help="init box x1,y1,x2,y2 in pixels of the first image (default with --images: the centred box [w/4, h/4, 3w/4, 3h/4]; synthetic clip: the box of oracle/synth.py)")
     ap.add_argument("--size", default="800x1280", help="network input HxW")
     ap.add_argument("--frames", type=int, default=2, help="current frames to check (after the reference frame)")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "fp32"])
@@ -72,9 +72,19 @@ def box_iou_pairs(a, b):
     return inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
 
 
+def _torch_load(path):
+    """tensors-only unpickling first (a checkpoint is a user-supplied file: the full unpickler executes arbitrary code); the released
+    files hold plain tensors + python scalars, so this succeeds for them; anything else falls back to the reference's own call with a note"""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:      # noqa: BLE001 -- older files with pickled objects
+        print("note: weights_only load of %s failed (%s); falling back to the full unpickler like tools/track.py:186" % (path, type(e).__name__), file=sys.stderr)
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_state(path):
     """tools/track.py:186-188"""
-    ckpt = torch.load(path, map_location="cpu")
+    ckpt = _torch_load(path)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt and isinstance(ckpt["model"], dict) else ckpt
     return {k: (v.float() if torch.is_floating_point(v) else v) for k, v in sd.items() if torch.is_tensor(v)}
 
@@ -102,7 +112,7 @@ def make_clip(args, H, W):
             out, r = lo.letterbox(img, (H, W), swap_rb=True)          # PreprocessorX.process
             frames.append(torch.from_numpy(np.ascontiguousarray(out)).float().view(1, 3, H, W))
         h0, w0 = np.load(args.images[0]).shape[:2]
-        box = torch.tensor([float(v) for v in args.box.split(",")]) if args.box else torch.tensor([w0 / 4, h0 / 4, w0 / 2, h0 / 2])
+        box = torch.tensor([float(v) for v in args.box.split(",")]) if args.box else torch.tensor([w0 / 4, h0 / 4, 3 * w0 / 4, 3 * h0 / 4])      # centred, half the image per side
         return frames, box * r
     import synth
     frames, box = synth.synth_clip(H, W, 1 + args.frames, seed=1)

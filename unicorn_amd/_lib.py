@@ -78,10 +78,53 @@ PROTOS = {
 }
 
 _lib = None
+BUILD_CHECK = None      # outcome of verify_manifest for the loaded library ("verified" / "no-sources" / "skipped")
 
 
 class UnicornHipError(RuntimeError):
     pass
+
+
+def verify_manifest(lib_name):
+    """The libraries are git-ignored build products that travel to the GPU box as files: unicorn_amd/csrc/build.sh writes
+    lib/build_manifest.json (sha256 of every source / header and of both libraries) and this check holds the library that is about to be
+    loaded, and the sources next to it (when the tree has them), to it -- a library that was not built from this tree's sources raises
+    instead of running stale kernels.  Returns "verified" / "no-sources" (deployment without csrc/).  UNI_SKIP_MANIFEST=1 turns the check into
+    a warning (local experiments with hand-built objects)."""
+    import hashlib
+    import json
+    import warnings
+
+    def sha(p):
+        with open(p, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+
+    def fail(msg):
+        msg = "%s -- rebuild with `python -c 'import __graft_entry__ as g; g.build()'`" % msg
+        if os.environ.get("UNI_SKIP_MANIFEST"):
+            warnings.warn(msg)
+            return "skipped"
+        raise UnicornHipError(msg)
+
+    mpath = os.path.join(_HERE, "lib", "build_manifest.json")
+    if not os.path.exists(mpath):
+        return fail("unicorn_amd/lib/build_manifest.json is missing (library built by hand?)")
+    man = json.load(open(mpath))
+    lpath = os.path.join(_HERE, "lib", lib_name)
+    if man.get("libs", {}).get(lib_name) != sha(lpath):
+        return fail("%s is not the library build_manifest.json describes" % lib_name)
+    csrc, inc = os.path.join(_HERE, "csrc"), os.path.join(os.path.dirname(_HERE), "include")
+    if not os.path.isdir(csrc):
+        return "no-sources"
+    for name, digest in man.get("sources", {}).items():
+        src = os.path.join(inc if name.startswith("unicorn_") and name.endswith(".h") else csrc, name)
+        if not os.path.exists(src) or sha(src) != digest:
+            return fail("%s changed since %s was built (stale library)" % (name, lib_name))
+    have = {f for f in os.listdir(csrc) if f.endswith(".h")} | {f for f in os.listdir(inc) if f.endswith(".h")}
+    new = sorted(have - set(man.get("sources", {})))
+    if new:
+        return fail("header(s) %s are newer than the build manifest" % ", ".join(new))
+    return "verified"
 
 
 def lib():
@@ -98,6 +141,8 @@ def lib():
             raise UnicornHipError(
                 "libunicorn_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU/PyTorch fallback for the Unicorn hot path)" % LIB_PATH)
+        global BUILD_CHECK
+        BUILD_CHECK = verify_manifest("libunicorn_hip.so")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOS.items():
             fn = getattr(L, name)      # AttributeError if a declared symbol is not exported

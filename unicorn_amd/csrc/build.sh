@@ -1,25 +1,47 @@
 #!/bin/bash
-# Build libunicorn_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# Build libunicorn_hip.so for gfx950 (MI355X) + the host-side association library.  hipcc cross-compiles without a GPU.
+# Incremental: a translation unit is rebuilt when it is older than its source or than ANY header (*.h here, include/*.h) -- a glob, not a list.
+# Writes ../lib/build_manifest.json (sha256 of every source / header -> the two libraries); unicorn_amd/_lib.py verifies it at load, so a
+# library that was not built from the sources next to it fails loudly instead of running stale code on the GPU box.
 set -e
 cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p $OUT build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+UNITS="gemm gemm_h2 gemm_h2d gemm_h2q gemm_p44 mlp_fused norm msda corr misc post mask_post engine api"
+HDRS=$(ls *.h ../../include/*.h)
 pids=()
-for f in gemm gemm_h2 gemm_h2d gemm_h2q gemm_p44 mlp_fused norm msda corr misc post mask_post engine api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ gemm_epi.h -nt build/$f.o ] || [ mask_interp.h -nt build/$f.o ] || [ ../../include/unicorn_hip.h -nt build/$f.o ]; then
+objs=()
+for f in $UNITS; do
+  objs+=(build/$f.o)
+  stale=0
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ]; then stale=1; fi
+  for h in $HDRS; do if [ $h -nt build/$f.o ]; then stale=1; fi; done
+  if [ $stale = 1 ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/gemm_h2.o build/gemm_h2d.o build/gemm_h2q.o build/gemm_p44.o build/mlp_fused.o build/norm.o build/msda.o build/corr.o build/misc.o build/post.o build/mask_post.o build/engine.o build/api.o -o $OUT/libunicorn_hip.so
+hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $OUT/libunicorn_hip.so
 echo "built $OUT/libunicorn_hip.so"
-# standalone measurement program (tools/feed_probe.hip: which path feeds a CU; profiles/r05_feed_probe.txt) -- not part of the library
-mkdir -p ../../tools/build
-if [ ! -f ../../tools/build/feed_probe ] || [ ../../tools/feed_probe.hip -nt ../../tools/build/feed_probe ]; then
-  hipcc --offload-arch=gfx950 -O3 -Wno-unused-value ../../tools/feed_probe.hip -o ../../tools/build/feed_probe
-fi
 # host-side association library (row N2): plain C++, no HIP
 g++ -O3 -std=c++17 -fPIC -shared -ffp-contract=off -o $OUT/libunicorn_assoc.so assoc.cpp
 echo "built $OUT/libunicorn_assoc.so"
+python3 - "$OUT" $UNITS <<'EOF'
+import hashlib, json, os, sys, glob
+out, units = sys.argv[1], sys.argv[2:]
+def sha(p):
+    return hashlib.sha256(open(p, "rb").read()).hexdigest()
+srcs = sorted([u + ".hip" for u in units] + ["assoc.cpp"] + glob.glob("*.h") + glob.glob("../../include/*.h"))
+man = {"sources": {os.path.basename(p): sha(p) for p in srcs},
+       "libs": {n: sha(os.path.join(out, n)) for n in ("libunicorn_hip.so", "libunicorn_assoc.so")}}
+json.dump(man, open(os.path.join(out, "build_manifest.json"), "w"), indent=1, sort_keys=True)
+print("wrote %s/build_manifest.json (%d sources)" % (out, len(srcs)))
+EOF
+# standalone measurement program (tools/feed_probe.hip: which path feeds a CU; profiles/r05_feed_probe.txt) -- not part of the library:
+# built last and non-fatally (a probe that does not compile on another ROCm must not leave the libraries unbuilt)
+mkdir -p ../../tools/build
+if [ ! -f ../../tools/build/feed_probe ] || [ ../../tools/feed_probe.hip -nt ../../tools/build/feed_probe ]; then
+  hipcc --offload-arch=gfx950 -O3 -Wno-unused-value ../../tools/feed_probe.hip -o ../../tools/build/feed_probe || echo "feed_probe skipped (does not build here)"
+fi

@@ -148,20 +148,45 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Guard for per-DEVICE one-time setup on the launch path (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property: a
 // `static bool` would leave the second GPU of a process without the opt-in, and an unguarded call is a driver call per launch).
-// first() is true once per (guard, current device); devices >= 64 share bit 63 with a re-set on every call (harmless).
+// run(setup) calls `setup` (-> hipError_t) until it has SUCCEEDED once per (guard, current device): the device's bit is set only after the
+// success, so a failing opt-in is retried and reported on every call (never a launch with more LDS than the kernel may use), and a second
+// thread that arrives while the first is still inside the driver call repeats the idempotent call itself instead of launching behind a
+// half-done opt-in.  Devices >= 64 are not tracked: the setup runs on every call there (harmless).
 struct DevOnce {
     std::atomic<uint64_t> mask{0};
-    bool first() {
+    template <class F>
+    hipError_t run(F&& setup) {
         int d = 0;
         (void)hipGetDevice(&d);
-        if (d >= 63) return true;
-        const uint64_t b = 1ull << d;
-        return !(mask.fetch_or(b, std::memory_order_relaxed) & b);
+        const bool tracked = d >= 0 && d < 64;
+        const uint64_t b = tracked ? 1ull << d : 0ull;
+        if (tracked && (mask.load(std::memory_order_acquire) & b)) return hipSuccess;
+        const hipError_t e = setup();
+        if (e == hipSuccess && tracked) mask.fetch_or(b, std::memory_order_release);
+        return e;
     }
 };
+// the > 64 KiB dynamic-LDS opt-in of one kernel instantiation
+static inline hipError_t uni_lds_optin(const void* fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
 
 // error plumbing (api.cpp owns the storage)
 void uni_set_error(const char* fmt, ...);
+// opt every listed kernel instantiation into `bytes` of dynamic LDS, once per device (DevOnce::run); `return -1` with an error text on failure
+#define UNI_LDS_OPTIN(once, what, bytes, ...)                                                                                   \
+    do {                                                                                                                        \
+        const hipError_t _oe = (once).run([&]() -> hipError_t {                                                                 \
+            const void* _fns[] = {__VA_ARGS__};                                                                                 \
+            for (const void* _f : _fns) {                                                                                       \
+                const hipError_t _e1 = uni_lds_optin(_f, (int)(bytes));                                                         \
+                if (_e1 != hipSuccess) return _e1;                                                                              \
+            }                                                                                                                   \
+            return hipSuccess;                                                                                                  \
+        });                                                                                                                     \
+        if (_oe != hipSuccess) {                                                                                                \
+            uni_set_error("%s: cannot reserve %d bytes of LDS (%s)", what, (int)(bytes), hipGetErrorString(_oe));               \
+            return -1;                                                                                                          \
+        }                                                                                                                       \
+    } while (0)
 #define UNI_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

@@ -327,10 +327,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
     static DevOnce attr_once;      // > 64 KiB dynamic LDS needs the opt-in attribute
-    if (lds > 65536 && attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    if (lds > 65536)
+        UNI_LDS_OPTIN(attr_once, "gemm_bf16", lds, reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>),
+                      reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>));
     if (a.stats) hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, true, NSTG>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, BK, CONV, false, NSTG>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return 0;

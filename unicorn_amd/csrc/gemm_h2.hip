@@ -290,10 +290,9 @@ static int launch_h2_cfg(const GemmArgs& a, hipStream_t s) {
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
     static DevOnce attr_once;
-    if (lds > 65536 && attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    if (lds > 65536)
+        UNI_LDS_OPTIN(attr_once, "gemm_h2", lds, reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>),
+                      reinterpret_cast<const void*>(&gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>));
     if (a.stats && gy == 1) hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, true, BKE>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, CONV, false, BKE>), dim3(grid, gy), dim3(64 * WM * WN), lds, s, a);
     if (gy > 1) return launch_splitk_reduce(a, s);

@@ -289,8 +289,7 @@ static int launch_h2d_spec(const GemmArgs& a, hipStream_t s) {      // producer 
     size_t lds = (size_t)NST * (BM + BN) * 128;
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);
     static DevOnce attr_once;
-    if (attr_once.first())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    UNI_LDS_OPTIN(attr_once, "gemm_h2d (producer waves)", lds, reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST, true>));
     hipLaunchKernelGGL((gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST, true>), dim3(grid), dim3(128 * WM * WN), lds, s, a);
     return 0;
 }
@@ -304,10 +303,8 @@ static int launch_h2d_cfg(const GemmArgs& a, hipStream_t s) {
     if (lds < (size_t)WM * WN * 32 * 32 * TN * sizeof(float)) lds = (size_t)WM * WN * 32 * 32 * TN * sizeof(float);   // staged epilogue
     if (lds < (WM * BN * 2 + 128) * sizeof(float)) lds = (WM * BN * 2 + 128) * sizeof(float);
     static DevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, true, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    UNI_LDS_OPTIN(attr_once, "gemm_h2d", lds, reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, true, NST>),
+                  reinterpret_cast<const void*>(&gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST>));
     if (a.stats && gy == 1) hipLaunchKernelGGL((gemm_h2d_kernel<WM, WN, TM, TN, CONV, true, NST>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
     else hipLaunchKernelGGL((gemm_h2d_kernel<WM, WN, TM, TN, CONV, false, NST>), dim3(grid, gy), dim3(64 * WM * WN), lds, s, a);
     if (gy > 1) return launch_splitk_reduce(a, s);

@@ -436,13 +436,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h2q_kernel(GemmArgs p) {
 template <int ACT, bool OUTF, bool CONV, bool STATS, int FMT>
 static int launch_h2q_inst(const GemmArgs& a, int grid, hipStream_t s) {
     static DevOnce attr_once;
-    if (attr_once.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF, CONV, STATS, FMT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            uni_set_error("gemm_h2q: cannot reserve %d bytes of LDS", LDS_BYTES);
-            return -1;
-        }
-    }
+    UNI_LDS_OPTIN(attr_once, "gemm_h2q", LDS_BYTES, reinterpret_cast<const void*>(&gemm_h2q_kernel<ACT, OUTF, CONV, STATS, FMT>));
     hipLaunchKernelGGL((gemm_h2q_kernel<ACT, OUTF, CONV, STATS, FMT>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
     return 0;
 }

@@ -246,13 +246,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_p44_kernel(GemmArgs p) {
 template <int ACT, bool OUTF>
 static int launch_p44_inst(const GemmArgs& a, int grid, hipStream_t s) {
     static DevOnce attr_once;
-    if (attr_once.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p44_kernel<ACT, OUTF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            uni_set_error("gemm_p44: cannot reserve %d bytes of LDS", LDS_BYTES);
-            return -1;
-        }
-    }
+    UNI_LDS_OPTIN(attr_once, "gemm_p44", LDS_BYTES, reinterpret_cast<const void*>(&gemm_bf16_p44_kernel<ACT, OUTF>));
     hipLaunchKernelGGL((gemm_bf16_p44_kernel<ACT, OUTF>), dim3(grid), dim3(64 * NW), LDS_BYTES, s, a);
     return 0;
 }

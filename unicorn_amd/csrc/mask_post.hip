@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void mask_resize_kernel(const float* __restric
 constexpr int CR_TX = 64, CR_TY = 32, CR_LDS = 12288;      // output tile, floats of LDS (48 KiB)
 template <bool STAGED>
 __global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __restrict__ coarse, int h, int w, int f, float rscale, int ho, int wo,
-                                                              int H, int W, float thr, float* __restrict__ outF, unsigned char* __restrict__ outU, int dbg) {
+                                                              int H, int W, float thr, float* __restrict__ outF, unsigned char* __restrict__ outU) {
     extern __shared__ float win[];                    // STAGED: the launcher's bound on a tile's window (<= CR_LDS floats; 4.3 KB at 1080p: 8 blocks per CU)
     const int n = blockIdx.z, x0t = blockIdx.x * CR_TX, y0t = blockIdx.y * CR_TY;
     const float* s = coarse + (size_t)n * h * w;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __res
         ww = src_index(xl, Wn, rscale).i1 - c0 + 1;
     }
     const bool staged = STAGED && any;              // (the launcher picks STAGED only when every tile's window fits: wh * ww <= CR_LDS)
-    if (staged && !(dbg & 1)) {      // a thread keeps its window column(s): the x coordinates once, no integer division per sample
+    if (staged) {      // a thread keeps its window column(s): the x coordinates once, no integer division per sample
         for (int xx = tx; xx < ww; xx += CR_TX) {
             int x0, x1;
             float fx;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void condinst_resize_kernel(const float* __res
                 for (int e = 0; e < 4; ++e)
                     if (xb + e < W) outF[o + e] = v[e];
             }
-            if (outU && !((dbg & 2) && v[0] != 12345.f)) {
+            if (outU) {
                 if (packed) {
                     *reinterpret_cast<unsigned*>(outU + o) = (v[0] > thr ? 1u : 0u) | (v[1] > thr ? 0x100u : 0u) | (v[2] > thr ? 0x10000u : 0u) | (v[3] > thr ? 0x1000000u : 0u);
                 } else {
@@ -394,9 +394,10 @@ int launch_condinst_resize(const float* coarse, int N, int h, int w, int f, floa
     const dim3 grid(cdiv(W, CR_TX), cdiv(H, CR_TY), N);
     // dynamic LDS = the window bound, not the 48 KiB maximum: a block lives for ~5 dependent L2 round trips (phase 1), so the kernel is bound
     // by the blocks in flight per CU (3 with a static 48 KiB array: 345 us for 64 masks; 8 with 4.3 KiB)
-    static const int dbg = getenv("UNI_CR_DBG") ? atoi(getenv("UNI_CR_DBG")) : 0;      // ablation (tools/mask_bench.py): 1 = no window evaluation, 2 = no byte stores
-    if (wh * ww <= CR_LDS) hipLaunchKernelGGL(condinst_resize_kernel<true>, grid, dim3(256), (size_t)(wh * ww) * sizeof(float), s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU, dbg);
-    else hipLaunchKernelGGL(condinst_resize_kernel<false>, grid, dim3(256), 0, s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU, dbg);
+    // (the UNI_CR_DBG ablation switches of round 5 -- no window evaluation / no byte stores -- are gone from the product kernel: a stray
+    // environment variable could make the default MOTS path return garbage; their measurements are in profiles/r05_mask_bench.txt)
+    if (wh * ww <= CR_LDS) hipLaunchKernelGGL(condinst_resize_kernel<true>, grid, dim3(256), (size_t)(wh * ww) * sizeof(float), s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU);
+    else hipLaunchKernelGGL(condinst_resize_kernel<false>, grid, dim3(256), 0, s, coarse, h, w, f, rscale, ho, wo, H, W, thr, outF, outU);
     return 0;
 }
 int launch_vos_merge(const float* probs, const int* prob_ids, int K1, int Hn, int Wn, float rscale, int ho, int wo,

@@ -760,12 +760,7 @@ template <int C, bool OUTB, int DBG>
 static int launch_mlp16_k(const MlpArgs& a, int grid, hipStream_t s) {
     constexpr int lds = Geo16<C>::LDS;
     static DevOnce attr_once;
-    if (attr_once.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused16_kernel<C, OUTB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            uni_set_error("mlp_fused16: cannot reserve %d bytes of LDS", lds);
-            return -1;
-        }
-    }
+    UNI_LDS_OPTIN(attr_once, "mlp_fused16", lds, reinterpret_cast<const void*>(&mlp_fused16_kernel<C, OUTB, DBG>));
     hipLaunchKernelGGL((mlp_fused16_kernel<C, OUTB, DBG>), dim3(grid), dim3(64 * MW16), lds, s, a);
     return 0;
 }
@@ -774,12 +769,7 @@ template <int C, int CH, bool OUTB, int DBG>
 static int launch_mlp_k(const MlpArgs& a, int grid, hipStream_t s) {
     constexpr int lds = Geo<C>::LDS;
     static DevOnce attr_once;
-    if (attr_once.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, CH, OUTB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            uni_set_error("mlp_fused: cannot reserve %d bytes of LDS", lds);
-            return -1;
-        }
-    }
+    UNI_LDS_OPTIN(attr_once, "mlp_fused", lds, reinterpret_cast<const void*>(&mlp_fused_kernel<C, CH, OUTB, DBG>));
     hipLaunchKernelGGL((mlp_fused_kernel<C, CH, OUTB, DBG>), dim3(grid), dim3(64 * MW), lds, s, a);
     return 0;
 }

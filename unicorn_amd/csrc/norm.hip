@@ -829,15 +829,13 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
             if (cdiv(nst, Sw) >= 384) {
                 static DevOnce attr_once;
 #define DWB_ALL(F) F(192, 2) F(256, 2) F(384, 2) F(512, 2) F(768, 2) F(192, 4) F(256, 4) F(384, 4) F(512, 4) F(768, 4)
-                if (attr_once.first()) {
-#define DWB_ATTR(CC, RR) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-                    DWB_ALL(DWB_ATTR)
+#define DWB_ATTR(CC, RR) reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, RR>),
+                UNI_LDS_OPTIN(attr_once, "dwconv7_lnb", 163840, DWB_ALL(DWB_ATTR) reinterpret_cast<const void*>(&dwconv7_lnb_kernel<768, 2>));
 #undef DWB_ATTR
-                }
                 const dim3 grid(256), block(Sw * wps * 64);
                 static const int dbg = getenv("UNI_DW_DBG") ? atoi(getenv("UNI_DW_DBG")) : 0;      // ablation builds of the stage-2 kernel (tools/dwln_bench.py)
                 if (dbg && a.C == 768 && rows == 2) {
-#define DWB_DBG(D) if (dbg == D) { static DevOnce once; if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<768, 2, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+#define DWB_DBG(D) if (dbg == D) { static DevOnce once; UNI_LDS_OPTIN(once, "dwconv7_lnb (ablation)", 163840, reinterpret_cast<const void*>(&dwconv7_lnb_kernel<768, 2, D>)); \
                                    hipLaunchKernelGGL((dwconv7_lnb_kernel<768, 2, D>), grid, block, ldsw, s, a, Sw, spr, nst); return 0; }
                     DWB_DBG(1) DWB_DBG(2) DWB_DBG(4) DWB_DBG(8) DWB_DBG(3) DWB_DBG(9) DWB_DBG(15)
 #undef DWB_DBG
@@ -855,7 +853,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                     const int gran = a.C == 384 ? 32 : 16;
                     const size_t ldsp = (size_t)49 * a.C * 4 + (size_t)2 * (nw * 64 / gran) * 16 * 4;
                     if (cdiv(nstg, Sg) >= 384) {
-#define DWB_PACK(CC, NWW) if (a.C == CC && nw == NWW) { static DevOnce once; if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, NWW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+#define DWB_PACK(CC, NWW) if (a.C == CC && nw == NWW) { static DevOnce once; UNI_LDS_OPTIN(once, "dwconv7_lnb (packed lanes)", 163840, reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, NWW, true>)); \
                                      hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, 2, 0, NWW, true>), grid, dim3(NWW * 64), ldsp, s, a, Sg, sprg, nstg); return 0; }
                         DWB_PACK(192, 6) DWB_PACK(192, 9) DWB_PACK(192, 12) DWB_PACK(384, 6) DWB_PACK(384, 9) DWB_PACK(384, 12)
 #undef DWB_PACK
@@ -867,7 +865,7 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
                 if (w12 && rows == 2 && (a.C == 384 || a.C == 768 || (w12 == 2 && a.C == 192))) {      // (C = 256 measured slower on 12 waves: 53.5 vs 45.2 us at 50 x 80)
                     const int Sw12 = 12 / wps;
                     const size_t lds12 = (size_t)49 * a.C * 4 + (size_t)2 * 12 * 16 * 4;
-#define DWB_W12(CC) if (a.C == CC) { static DevOnce once; if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+#define DWB_W12(CC) if (a.C == CC) { static DevOnce once; UNI_LDS_OPTIN(once, "dwconv7_lnb (12 waves)", 163840, reinterpret_cast<const void*>(&dwconv7_lnb_kernel<CC, 2, 0, 12>)); \
                                      hipLaunchKernelGGL((dwconv7_lnb_kernel<CC, 2, 0, 12>), grid, dim3(Sw12 * wps * 64), lds12, s, a, Sw12, spr, nst); return 0; }
                     DWB_W12(192) DWB_W12(384) DWB_W12(768)
 #undef DWB_W12

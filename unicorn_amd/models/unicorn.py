@@ -136,6 +136,8 @@ class Unicorn(torch.nn.Module):
     themselves live re-packed inside the context (csrc/engine.hip), not as torch parameters: `state_dict()` returns the anchor only,
     `load_state_dict` takes the reference checkpoint namespace.  `torch.jit.trace` cannot see through the C-ABI calls and raises."""
 
+    _half_warned = False      # .half() explains itself once per process
+
     def __init__(self, name_or_cfg="unicorn_track_tiny", device=None, precision="f16x2"):
         """precision (operand format of every dense contraction; accumulation, residual stream and statistics are fp32):
           "f16x2"  (default) fp32-equivalent: operands split into hi + lo f16 halves, 3 f16 MFMAs per product (22 operand bits).
@@ -212,7 +214,14 @@ class Unicorn(torch.nn.Module):
 
     def half(self):
         # tools/track.py --fp16 calls model.half() and feeds half images (mot_evaluator.py:126-128): the operand format of the HIP
-        # path is fixed by `precision` at construction, inputs are widened to fp32 (forward_backbone), so this is a no-op
+        # path is fixed by `precision` at construction, inputs are widened to fp32 (forward_backbone), so this is a no-op -- said ONCE,
+        # because a --fp16 user otherwise pays the fp32-equivalent cost without knowing why nothing got faster
+        if not Unicorn._half_warned:
+            Unicorn._half_warned = True
+            import warnings
+            warnings.warn("unicorn_amd: model.half() does not change the arithmetic -- the operand format is fixed by `precision=%r` at "
+                          "construction (f16x2 = fp32-equivalent split-f16 MFMA operands; half inputs are widened to fp32).  A single-f16 or "
+                          "bf16 path cannot meet the box IoU >= 0.999 parity bar (DESIGN.md section 2)." % (self.precision,), stacklevel=2)
         return self
 
     def check_saturation(self, on=True):

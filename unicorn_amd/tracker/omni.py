@@ -314,3 +314,72 @@ class OmniMOTSFrame(OmniMOTFrame):
         """as OmniMOTFrame.run_stream, with the C stage (overlap-free + RLE) of frame t enqueued right after its association and
         collected after B of the next frame and A of a later frame are in the queue"""
         return super().run_stream(frames, info_img)
+
+
+class ByteMOTFrame(OmniMOTFrame):
+    """Loop body of `MOTEvaluator.evaluate` (unicorn/evaluators/mot_evaluator.py:198-222) = what `tools/track.py` runs per frame:
+    `outputs, _ = model(imgs)` (mode="whole", :199) -> `postprocess(outputs, num_classes, confthre, nmsthre)` (:203) ->
+    `tracker.update(outputs[0], info_imgs, img_size)` (:212, the native BYTETracker) -> tracks with `tlwh[2] * tlwh[3] > min_box_area` that are
+    not `vertical` (w / h > 1.6) (:216-222).  No embeddings, no interaction: stage B is only the survivor rows' copy to the host.
+    `run(imgs, info_imgs)` -> (online_tlwhs, online_ids, online_scores) or None for a frame without detections (:211: the tracker is not
+    stepped then); `run_stream` pipelines `whole` of later frames over the host association exactly like the `evaluate_omni` loop."""
+
+    def __init__(self, model, tracker, img_size, num_classes=1, confthre=0.01, nmsthre=0.7, min_box_area=100, timer=None):
+        super().__init__(model, tracker, img_size, num_classes, confthre, nmsthre, 0.0, timer)
+        self.min_box_area = min_box_area                                                    # tools/track.py:110
+
+    def _stage_b(self, tk):
+        tk.rows = []
+        for p in tk.post:
+            det = postprocess_collect(p)[0]
+            tk.rows.append(None if det is None else self._pin.to_pinned(det))               # (N, 7) [x1 y1 x2 y2 obj cls_conf cls]  boxes.py:71
+        self.t.mark("rows")
+        tk.ev_b = torch.cuda.Event()
+        tk.ev_b.record()
+
+    def _host_assoc(self, tk):
+        tk.ev_b.synchronize()
+        self.t.mark("d2h")
+        tk.res = []
+        for rows in tk.rows:
+            self.frame_id += 1
+            if rows is None:
+                tk.res.append(None)
+                continue
+            det, base = rows
+            targets = self.tracker.update(det.numpy(), tk.info, self.img_size)              # :212
+            self._pin.release(base)
+            tlwhs, ids, scores = [], [], []
+            for t in targets:                                                               # :216-222
+                tlwh = t.tlwh
+                vertical = tlwh[2] / tlwh[3] > 1.6
+                if tlwh[2] * tlwh[3] > self.min_box_area and not vertical:
+                    tlwhs.append(tlwh)
+                    ids.append(t.track_id)
+                    scores.append(t.score)
+            tk.res.append((tlwhs, ids, scores))
+        self.t.mark("association")
+
+
+class DemoPredictor:
+    """`Predictor.inference` of tools/demo.py:136-172 for the detection / tracking experiments (`exp.task != "inst"`): letterbox
+    (`ValTransform` = preproc, data_augment.py:194-214, no mean / std) -> `outputs, seq_dict = model(img)` (mode="whole", :166; the file as shipped
+    has a dangling `try / except` there) -> `postprocess(outputs, num_classes, confthre, nmsthre, class_agnostic=True)`
+    (:169-172).  `inference(img)` takes the HWC uint8 BGR image (cv2.imread's layout) -> (outputs list, img_info) like the reference; the
+    letterbox runs on the device (uni_letterbox)."""
+
+    def __init__(self, model, num_classes, confthre, nmsthre, test_size):
+        self.model, self.num_classes, self.confthre, self.nmsthre, self.test_size = model, num_classes, confthre, nmsthre, tuple(test_size)
+
+    def inference(self, img):
+        from ..ops import letterbox
+        from ..utils.boxes import postprocess
+        height, width = img.shape[:2]
+        ratio = min(self.test_size[0] / img.shape[0], self.test_size[1] / img.shape[1])      # :150
+        img_info = {"id": 0, "file_name": None, "height": height, "width": width, "raw_img": img, "ratio": ratio}
+        x, _ = letterbox(torch.as_tensor(img).cuda(), self.test_size, swap_rb=False)         # ValTransform: BGR kept, pad 114, CHW fp32 0-255
+        with torch.no_grad():
+            outputs, _ = self.model(x)                                                       # :166
+            out = outputs[0] if isinstance(outputs, tuple) else outputs
+            dets = postprocess(out, self.num_classes, self.confthre, self.nmsthre, class_agnostic=True)      # :169-172
+        return dets, img_info

@@ -31,6 +31,11 @@ def assoc_lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             raise UnicornAssocError("native association library missing: %s (run __graft_entry__.build())" % _LIB_PATH)
+        from .._lib import verify_manifest, UnicornHipError
+        try:
+            verify_manifest("libunicorn_assoc.so")      # built from this tree's assoc.cpp (csrc/build.sh manifest)
+        except UnicornHipError as e:
+            raise UnicornAssocError(str(e))
         L = C.CDLL(_LIB_PATH)
         L.uni_qd_default_cfg.argtypes = [C.POINTER(_Cfg)]
         L.uni_qd_default_cfg.restype = None

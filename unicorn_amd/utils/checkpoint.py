@@ -137,7 +137,10 @@ def load_ckpt(model, ckpt):
 
 def load_checkpoint_file(model, path, strict=False):
     """tools/track.py:186-188: ckpt = torch.load(file, map_location="cpu"); model.load_state_dict(ckpt["model"], strict=False)"""
-    ckpt = torch.load(path, map_location="cpu")
+    try:                                                            # tensors-only unpickling first: the file is user-supplied
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:                                               # noqa: BLE001 -- pickled python objects: the reference's own call
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
     return model.load_state_dict(sd, strict=strict)
 
