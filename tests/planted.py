@@ -26,15 +26,16 @@ def planted_pred(A, nc, seed, n_clusters=40, per=12):
     return pred
 
 
-def confident_head(P, obj_bias=1.0, cls_bias=1.0):
+def confident_head(P, obj_bias=1.0, cls_bias=1.0, spread=1.0):
     """Synthetic weights give obj * cls ~ 1e-4 (prediction biases at -4.6, exp/unicorn_track.py:146); loops whose logic runs on score thresholds
-    (BYTETracker: track_thresh, the 0.1 low-score floor, det_thresh) need detector-like scores.  Shift the obj / cls prediction biases so that
-    scores spread around sigmoid(obj_bias) * sigmoid(cls_bias) (the feature-dependent part of the logits keeps its spread) -> new state dict."""
+    (BYTETracker: track_thresh, the 0.1 low-score floor, det_thresh = track_thresh + 0.1) need detector-like scores.  Shift the obj / cls prediction
+    biases so that scores sit around sigmoid(obj_bias) * sigmoid(cls_bias) and scale the obj / cls prediction WEIGHTS by `spread` (the
+    feature-dependent part of the logits: a wider score distribution) -> new state dict."""
     Q = dict(P)
     for k in P:
-        if k.startswith("head.") and k.endswith(".bias"):
-            if ".obj_preds" in k:
-                Q[k] = torch.full_like(P[k], obj_bias)
-            elif ".cls_preds" in k:
-                Q[k] = torch.full_like(P[k], cls_bias)
+        if k.startswith("head.") and (".obj_preds" in k or ".cls_preds" in k):
+            if k.endswith(".bias"):
+                Q[k] = torch.full_like(P[k], obj_bias if ".obj_preds" in k else cls_bias)
+            elif k.endswith(".weight") and spread != 1.0:
+                Q[k] = P[k] * spread
     return Q

@@ -116,7 +116,10 @@ def verify_manifest(lib_name):
     csrc, inc = os.path.join(_HERE, "csrc"), os.path.join(os.path.dirname(_HERE), "include")
     if not os.path.isdir(csrc):
         return "no-sources"
+    assoc_srcs = ("assoc.cpp", "unicorn_assoc.h")                  # the host-side association library is built from these two only
     for name, digest in man.get("sources", {}).items():
+        if (name in assoc_srcs) != (lib_name == "libunicorn_assoc.so"):
+            continue
         src = os.path.join(inc if name.startswith("unicorn_") and name.endswith(".h") else csrc, name)
         if not os.path.exists(src) or sha(src) != digest:
             return fail("%s changed since %s was built (stale library)" % (name, lib_name))

@@ -50,11 +50,12 @@ inline float iou(const Box& a, const Box& b) {
     return inter / (area_a + area_b - inter);
 }
 // Similarity matrix f[i][j] = <x_i, y_j> (x: m rows, y: M rows, both contiguous [.][dim]); the reference calls torch.mm here.  Every
-// f[i][j] is ONE fp32 accumulator running over d in ascending order (no FMA contraction: -ffp-contract=off) -- the plain scalar chain --
-// but the loop nest puts j innermost over a transposed copy of y, so the compiler vectorises ACROSS memory rows: same bits on every
-// machine and vector width, ~10x the speed of the scalar chains (which took ~3 ms per frame for 100 detections x 250 memory rows x 256
-// dims: 60 % of the evaluate_omni association stage).
-__attribute__((target_clones("avx512f", "avx2", "default")))
+// f[i][j] is ONE fp32 accumulator running over d in ascending order through std::fma (exactly rounded on every machine: vfmadd in the avx clones, the
+// correctly rounded libm fmaf in the baseline clone, so the clones agree bit for bit); the loop nest puts j innermost over a transposed copy of y, so
+// the compiler vectorises ACROSS memory rows.  Round 6: FOUR detections per pass (each y load feeds four accumulator sets: 8 FMAs per 2 loads + 4
+// broadcasts = the FMA ports are the limit) and fused multiply-adds instead of the mul + add pairs of -ffp-contract=off: 285 -> ~110 us per frame at
+// 200 detections x 400 memory rows x 128 dims (rounds 1-3: scalar chains, ~3 ms per frame for 100 x 250 x 256).
+__attribute__((target_clones("avx512f", "avx2,fma", "default")))
 void dot_matrix(const float* x, int m, const float* y, int M, int dim, float* f) {
     constexpr int JB = 32;                                   // memory rows per block: [d][JB] image of 128 B x dim stays in L1 across all i
     const int nb = (M + JB - 1) / JB;
@@ -67,17 +68,29 @@ void dot_matrix(const float* x, int m, const float* y, int M, int dim, float* f)
         const float* yb = yt.data() + (size_t)b * dim * JB;
         const int jn = std::min(JB, M - b * JB);
         int i = 0;
-        for (; i + 2 <= m; i += 2) {                         // two detections per pass: each y load feeds two accumulator sets
+        for (; i + 4 <= m; i += 4) {
             const float* x0 = x + (size_t)i * dim;
             const float* x1 = x0 + dim;
-            float a0[JB], a1[JB];
-            for (int k = 0; k < JB; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+            const float* x2 = x1 + dim;
+            const float* x3 = x2 + dim;
+            float a0[JB], a1[JB], a2[JB], a3[JB];
+            for (int k = 0; k < JB; ++k) { a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; a3[k] = 0.f; }
             for (int d = 0; d < dim; ++d) {
-                const float v0 = x0[d], v1 = x1[d];
+                const float v0 = x0[d], v1 = x1[d], v2 = x2[d], v3 = x3[d];
                 const float* yr = yb + (size_t)d * JB;
-                for (int k = 0; k < JB; ++k) { a0[k] += v0 * yr[k]; a1[k] += v1 * yr[k]; }
+                for (int k = 0; k < JB; ++k) {
+                    a0[k] = std::fma(v0, yr[k], a0[k]);
+                    a1[k] = std::fma(v1, yr[k], a1[k]);
+                    a2[k] = std::fma(v2, yr[k], a2[k]);
+                    a3[k] = std::fma(v3, yr[k], a3[k]);
+                }
             }
-            for (int k = 0; k < jn; ++k) { f[(size_t)i * M + b * JB + k] = a0[k]; f[(size_t)(i + 1) * M + b * JB + k] = a1[k]; }
+            for (int k = 0; k < jn; ++k) {
+                f[(size_t)i * M + b * JB + k] = a0[k];
+                f[(size_t)(i + 1) * M + b * JB + k] = a1[k];
+                f[(size_t)(i + 2) * M + b * JB + k] = a2[k];
+                f[(size_t)(i + 3) * M + b * JB + k] = a3[k];
+            }
         }
         for (; i < m; ++i) {
             const float* x0 = x + (size_t)i * dim;
@@ -86,7 +99,7 @@ void dot_matrix(const float* x, int m, const float* y, int M, int dim, float* f)
             for (int d = 0; d < dim; ++d) {
                 const float v0 = x0[d];
                 const float* yr = yb + (size_t)d * JB;
-                for (int k = 0; k < JB; ++k) a0[k] += v0 * yr[k];
+                for (int k = 0; k < JB; ++k) a0[k] = std::fma(v0, yr[k], a0[k]);
             }
             for (int k = 0; k < jn; ++k) f[(size_t)i * M + b * JB + k] = a0[k];
         }
@@ -129,11 +142,21 @@ void softmax_scores(float* f, float* sc, int m, int M, bool bi) {
     for (int i = 0; i < m; ++i) {
         const float* fi = f + (size_t)i * M;
         float* si = sc + (size_t)i * M;
-        float mx = -INFINITY, s = 0.f;
+        float mx = -INFINITY;
         for (int j = 0; j < M; ++j) mx = std::max(mx, fi[j]);
         for (int j = 0; j < M; ++j) si[j] = exp_neg(fi[j] - mx);          // (vectorises: no reduction in this loop)
-        for (int j = 0; j < M; ++j) s += si[j];                              // sum in index order
-        for (int j = 0; j < M; ++j) si[j] /= s;
+        // row sum: 16 interleaved chains (chain k takes j = k mod 16, ascending), folded in a fixed order -- the same additions at any vector width,
+        // so the clones agree bit for bit (a single scalar chain is latency-bound: 4 cycles per element, ~100 us per frame at 200 x 400)
+        float ch[16];
+        for (int k = 0; k < 16; ++k) ch[k] = 0.f;
+        int j = 0;
+        for (; j + 16 <= M; j += 16)
+            for (int k = 0; k < 16; ++k) ch[k] += si[j + k];
+        for (int k = 0; j < M; ++j, ++k) ch[k] += si[j];
+        for (int w = 8; w >= 1; w >>= 1)
+            for (int k = 0; k < w; ++k) ch[k] += ch[k + w];
+        const float s = ch[0];
+        for (int j2 = 0; j2 < M; ++j2) si[j2] /= s;
     }
     if (!bi) return;
     // the column softmax walks the matrix ROW by row (j innermost: contiguous, vectorised); every column still takes its maximum and its
@@ -270,21 +293,29 @@ int uni_qd_match(uni_qd* t, const float* bboxes_in, const int64_t* labels_in, co
             // softmax over dim 1 (d2t) and, for bisoftmax, dim 0 (t2d): exp(x - max) / sum  (:166-173)
             softmax_scores(f.data(), sc.data(), m, M, c.match_metric == 0);
         }
-        if (c.with_cats)                                                // :182-184
-            for (int i = 0; i < m; ++i)
-                for (int j = 0; j < M; ++j)
-                    if (lab[i] != mlab[j]) sc[(size_t)i * M + j] *= 0.f;
-        for (int i = 0; i < m; ++i) {                                   // greedy assignment (:186-194)
+        // :182-194.  `scores *= cat_same` (:182-184) and the column clearing of the greedy loop (`scores[:i, memo_ind] = 0; scores[i+1:, memo_ind] = 0`,
+        // :190-191) are applied WHILE a row is scanned instead of being written into the matrix: row i sees 0 in a column whose category differs
+        // (x * 0.f: a NaN score stays NaN like in the reference) or that an earlier row took -- rows above i are never read again, so a strided
+        // column store per match (200 x 200 cache lines per frame) buys nothing.  torch.max semantics: the FIRST maximum.
+        std::vector<float> taken(M, 1.f), rowv(M);
+        for (int i = 0; i < m; ++i) {
+            const float* si = sc.data() + (size_t)i * M;
+            if (c.with_cats) {
+                const int64_t li = lab[i];
+                for (int j = 0; j < M; ++j) rowv[j] = (mlab[j] != li ? si[j] * 0.f : si[j]);
+            } else {
+                for (int j = 0; j < M; ++j) rowv[j] = si[j];
+            }
+            for (int j = 0; j < M; ++j) rowv[j] = taken[j] == 0.f ? 0.f : rowv[j];
             int best = 0;
-            float conf = sc[(size_t)i * M];
+            float conf = rowv[0];
             for (int j = 1; j < M; ++j)
-                if (sc[(size_t)i * M + j] > conf) { conf = sc[(size_t)i * M + j]; best = j; }   // torch.max: first maximum
+                if (rowv[j] > conf) { conf = rowv[j]; best = j; }
             const int64_t id = mid[best];
             if (conf > c.match_score_thr && id > -1) {
                 if (b[i].v[4] > c.obj_score_thr) {
                     ids[i] = id;
-                    for (int r = 0; r < m; ++r)
-                        if (r != i) sc[(size_t)r * M + best] = 0.f;
+                    taken[best] = 0.f;
                 } else if (conf > c.nms_conf_thr) {
                     ids[i] = -2;
                 }

@@ -798,6 +798,166 @@ __global__ __launch_bounds__(NW * 64) void dwconv7_lnb_kernel(DwLnArgs p, int S,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE FRAME PER CALL (round 6): depthwise 7x7 + LayerNorm on a map with too few strips for the persistent kernel above (50 x 80 x 768 of one
+// frame = 250 strips of 2 rows x 8 px).  With ~1 wave per SIMD nothing hides the L2 round trip of an input row behind another wave, and a thread
+// that walks the 7 (8) rows of its window pays them one after the other (dwconv7_ln_kernel<8>: 18.7-20.8 us per launch, 27 launches per frame;
+// the LDS-tap kernel with one strip per block, one wave per SIMD: 26.9 us -- measured, round 6).  Here the 8 input rows of a strip are SPLIT over
+// FOUR WAVE GROUPS of one block (group g takes rows 2g, 2g + 1 for both output rows: 3 / 4 / 4 / 3 tap rows), so a wave's dependent chain is two
+// rows long and a CU holds 12 waves (three per SIMD) of the same strip; groups 1-3 park their partial sums in LDS ([group][pixel][lane] float4:
+// conflict-free 16-byte accesses), group 0 adds them in a fixed order (deterministic), runs the two-pass LayerNorm (in-wave reduce-scatter
+// butterfly + one LDS exchange between its waves) and stores.  Taps come straight from global memory (L2-resident 49 x C table, read once per
+// block like every other variant).  C = 768 (12 waves); <= 168 registers.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(C) void dwconv7_lns_kernel(DwLnArgs p, int spr, int nstrips) {
+    constexpr int PX = 8, IN = PX + 6, CG = C / 4, WPG = CG / 64;      // waves per group
+    static_assert(CG % 64 == 0 && 4 * WPG <= 16, "row-split kernel: C a multiple of 256, at most 16 waves");
+    extern __shared__ float lds[];
+    f32x4* part = reinterpret_cast<f32x4*>(lds);                       // [3][16][CG]
+    float* red = lds + 3 * 16 * CG * 4;                                // [2][WPG][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid / CG);            // row group (wave-uniform: CG is a multiple of 64)
+    const int cg = tid - g * CG, wv = cg >> 6;
+    int blk;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    if (blk >= nstrips) return;                                        // (whole block)
+    const int HP = (p.H + 1) >> 1;
+    const int yg = blk / spr, x0 = (blk - yg * spr) * PX;
+    const int sb = yg / HP, y = (yg - sb * HP) * 2;
+    const size_t img0 = (size_t)sb * p.H * p.W;
+    const int rowbytes = p.W * C * 4;
+    f32x4 acc[2][PX];
+    {
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + cg * 4);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int o = 0; o < PX; ++o) acc[q][o] = g == 0 ? bias4 : z;
+    }
+    auto mac = [&](f32x4 (&a)[PX], const f32x4 (&w)[7], const f32x4 (&src)[IN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+            for (int o = 0; o < PX; ++o)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[o][e] = fmaf(w[kx][e], src[o + kx][e], a[o][e]);
+    };
+    auto taps = [&](f32x4 (&w)[7], int ky) __attribute__((always_inline)) {
+        const float* wrow = p.w + (size_t)(ky * 7) * C + cg * 4;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) w[kx] = *reinterpret_cast<const f32x4*>(wrow + (size_t)kx * C);
+    };
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * g + rr, iy = y - 3 + r;                      // window row r: tap row r for output row y, r - 1 for y + 1
+        f32x4 row[IN];
+        {
+            const bool rok = iy >= 0 && iy < p.H;
+            float* rowp = const_cast<float*>(p.x) + (img0 + (size_t)(rok ? iy : 0) * p.W) * C;
+#pragma unroll
+            for (int j = 0; j < IN; ++j) {                             // zero padding = a descriptor with no records (wave-uniform)
+                const int ix = x0 + j - 3;
+                const bool ok = rok && ix >= 0 && ix < p.W;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, ok ? rowbytes : 0, 0x00020000);
+                row[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, cg * 16, ok ? ix * C * 4 : 0, 0));
+            }
+        }
+        if (r <= 6) {
+            f32x4 w[7];
+            taps(w, r);
+            mac(acc[0], w, row);
+        }
+        if (r >= 1) {
+            f32x4 w[7];
+            taps(w, r - 1);
+            mac(acc[1], w, row);
+        }
+    }
+    // partial sums of groups 1..3 -> LDS, group 0 adds them in group order
+    if (g > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[((g - 1) * 16 + u) * CG + cg] = acc[u >> 3][u & 7];
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 v = part[(k * 16 + u) * CG + cg];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u >> 3][u & 7][e] += v[e];
+            }
+    }
+    // LayerNorm over the C channels of each of the 16 pixels (group 0 computes; every wave takes the barriers)
+    auto wave_scatter_sum = [&](const float (&v)[16]) __attribute__((always_inline)) {       // -> lane holds the wave total of value (lane >> 2) & 15
+        float a8[8], a4[4], a2[2], a1;
+        { const bool up = (lane >> 5) & 1;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) a8[r] = (up ? v[r + 8] : v[r]) + __shfl_xor(up ? v[r] : v[r + 8], 32, 64); }
+        { const bool up = (lane >> 4) & 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a4[r] = (up ? a8[r + 4] : a8[r]) + __shfl_xor(up ? a8[r] : a8[r + 4], 16, 64); }
+        { const bool up = (lane >> 3) & 1;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) a2[r] = (up ? a4[r + 2] : a4[r]) + __shfl_xor(up ? a4[r] : a4[r + 2], 8, 64); }
+        { const bool up = (lane >> 2) & 1;
+          a1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 4, 64); }
+        a1 += __shfl_xor(a1, 2, 64);
+        a1 += __shfl_xor(a1, 1, 64);
+        return a1;
+    };
+    auto reduce16 = [&](const float (&pt)[16], float (&tot)[16], int buf) __attribute__((always_inline)) {
+        float* rb = red + buf * (WPG * 16);
+        if (g == 0) {
+            const float t = wave_scatter_sum(pt);
+            if ((lane & 3) == 0) rb[wv * 16 + ((lane >> 2) & 15)] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 16; ++o) tot[o] = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WPG; ++w_)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(rb + w_ * 16 + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[4 * g4 + e] += v4[e];
+            }
+    };
+    constexpr float invC = 1.f / (float)C;
+    float pt[16], tot[16], mean[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const f32x4 v = acc[u >> 3][u & 7]; pt[u] = v[0] + v[1] + v[2] + v[3]; }
+    reduce16(pt, tot, 0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        mean[u] = tot[u] * invC;
+        const f32x4 v = acc[u >> 3][u & 7];
+        const float a = v[0] - mean[u], b = v[1] - mean[u], c = v[2] - mean[u], d = v[3] - mean[u];
+        pt[u] = a * a + b * b + c * c + d * d;
+    }
+    reduce16(pt, tot, 1);
+    if (g != 0) return;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + cg * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cg * 4);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int q = u >> 3, o = u & 7;
+        if (y + q < p.H && x0 + o < p.W) {
+            const float rstd = rsqrtf(tot[u] * invC + p.eps), m = mean[u];
+            const f32x4 v = acc[q][o];
+            act_store4(p.out, (img0 + (size_t)(y + q) * p.W + x0 + o) * C + cg * 4, (v[0] - m) * rstd * gm[0] + be[0], (v[1] - m) * rstd * gm[1] + be[1],
+                       (v[2] - m) * rstd * gm[2] + be[2], (v[3] - m) * rstd * gm[3] + be[3], p.b32);
+        }
+    }
+}
+
 int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     UNI_REQUIRE(a.C % 4 == 0 && a.C / 4 <= 512, "dwconv7_ln: C=%d unsupported", a.C);
     const int CG = a.C / 4;
@@ -811,6 +971,18 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     const long n8 = (long)cdiv(a.W, 8) * a.H * nb * CG;
     int px = n8 >= 150000L ? 16 : n8 >= 70000L ? 8 : 4;
     if (env) px = atoi(env);
+    // one frame per call, C = 768: the row-split kernel (above) while the map has at most ~2 rounds of one-strip blocks; UNI_DW_SPLIT=0 = A/B switch
+    static const int split_env = getenv("UNI_DW_SPLIT") ? atoi(getenv("UNI_DW_SPLIT")) : 1;
+    if (split_env && !env && a.C == 768 && (long)a.W * a.C * 4 < (1L << 30)) {
+        const int spr = cdiv(a.W, 8), nst = spr * cdiv(a.H, 2) * nb;
+        if (nst <= 512) {
+            constexpr int ldsb = 3 * 16 * 192 * 16 + 2 * 3 * 16 * 4;
+            static DevOnce once;
+            UNI_LDS_OPTIN(once, "dwconv7_lns", ldsb, reinterpret_cast<const void*>(&dwconv7_lns_kernel<768>));
+            hipLaunchKernelGGL((dwconv7_lns_kernel<768>), dim3(nst), dim3(768), ldsb, s, a, spr, nst);
+            return 0;
+        }
+    }
     if (px == 16) {
         const int spr = cdiv(a.W, 8), nstrips = spr * ((a.H + 1) / 2) * nb;
         // persistent variant (row descriptors, register double buffer, weights in LDS): C a multiple of 256, 49 C floats + scratch
