@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (clean per-kernel averages under rocprofv3)")
     ap.add_argument("--with-bf16", action="store_true", help="also time the bf16 operand mode (1 MFMA per product).  Retired from the default line: it "
                     "misses the box-IoU bar with the synthetic AND the trained-like weight ensembles (profiles/r04_precision_budget_trained_like_*.json)")
+    ap.add_argument("--torch-rocm-port", action="store_true", help="also time the oracle port through PLAIN PyTorch-ROCm (eager MIOpen / rocBLAS ops, fp32 and "
+                    ".half()) on this GPU, in a child process with a timeout; reported inside cpu_baseline as context (what the hand-written path is worth "
+                    "next to the framework's own kernels) -- never `value`")
+    ap.add_argument("--torch-rocm-port-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help="only rendezvous (gloo on CPU, RCCL on GPUs) and report the world size")
     return ap.parse_args()
 
@@ -74,6 +78,63 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def torch_rocm_port_child(args):
+    """`bench.py --torch-rocm-port-child`: the oracle (oracle/unicorn_oracle.py, the pinned restatement of the reference's fp32 PyTorch path; MSDA through
+    the reference's pure-PyTorch grid_sample formulation, ops/functions/ms_deform_attn_func.py:41-61) executed by PyTorch-ROCm's own eager kernels on cuda:0:
+    the same SOT step, same synthetic weights and frames, fp32 and (if it runs) with .half() weights / inputs like `tools/track.py --fp16`.  The reference
+    tree itself cannot travel to the GPU box; this is its port on the framework's kernels.  Baseline leg only (never the product path).  Prints one JSON line."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import synth
+    import unicorn_oracle as uo
+    dev = torch.device("cuda:0")
+    H, W = args.height, args.width
+    cfg = uo.CONFIGS[args.model]
+    P32 = {k: v.to(dev) for k, v in synth.synth_state_dict(cfg).items()}
+    frames, box = synth.synth_clip(H, W, 4, seed=1)
+    out = {"model": args.model, "size": [H, W], "torch": torch.__version__, "device": torch.cuda.get_device_name(0)}
+    fr32 = [f.to(dev) for f in frames]
+
+    def timed(fn):
+        with torch.no_grad(), torch.device(dev):
+            t0 = time.perf_counter()
+            for i in range(2):
+                fn(i)
+            torch.cuda.synchronize()
+            warm = time.perf_counter() - t0
+            ts = []
+            for i in range(args.cpu_frames + 2):
+                t1 = time.perf_counter()
+                r = fn(i)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+        ts.sort()
+        return r, {"ms_per_frame_min": round(1e3 * ts[0], 2), "ms_per_frame_median": round(1e3 * ts[len(ts) // 2], 2), "fps": round(1.0 / ts[len(ts) // 2], 2),
+                   "frames": len(ts), "warmup_s_incl_kernel_selection": round(warm, 1)}
+    # (1) the SOT step (unicorn_sot.py:78-108), fp32 -- the reference SOT driver keeps the model in fp32 (only the correlation is cast to fp16)
+    try:
+        with torch.no_grad(), torch.device(dev):
+            st = uo.sot_init(P32, cfg, fr32[0], box.to(dev))
+        r, out["sot_step_fp32"] = timed(lambda i: uo.sot_step(P32, cfg, st, fr32[1 + i % 3]))
+        hd = r["head"][0] if cfg.mask else r["head"]
+        out["sot_step_fp32"]["finite"] = bool(torch.isfinite(hd.float()).all())
+    except Exception as e:                      # noqa: BLE001
+        out["sot_step_fp32"] = {"error": repr(e)[:300]}
+    # (2) mode="whole" (backbone + FPN + head: the MOT entry, mot_evaluator.py:199), fp32 and with .half() weights / inputs = `tools/track.py --fp16`
+    # (mot_evaluator.py:126-128; the interaction is never run in half by the reference: its MSDA op dispatches float / double only)
+    for name, cast in (("whole_fp32", lambda t: t), ("whole_half", lambda t: t.half() if torch.is_floating_point(t) else t)):
+        try:
+            P = {k: cast(v) for k, v in P32.items()}
+            fr = [cast(f) for f in fr32]
+            r, out[name] = timed(lambda i: uo.mot_whole(P, cfg, fr[1 + i % 3]))
+            hd = r[0][0] if cfg.mask else r[0]
+            out[name]["finite"] = bool(torch.isfinite(hd.float()).all())
+        except Exception as e:                  # noqa: BLE001 -- e.g. an op without a half kernel: reported, not fatal
+            out[name] = {"error": repr(e)[:300]}
+    print(json.dumps(out), flush=True)
+    sys.exit(0)
 
 
 def rccl_probe_child():
@@ -470,6 +531,8 @@ def main():
     args = parse()
     if args.rccl_probe:
         rccl_probe_child()
+    if args.torch_rocm_port_child:
+        torch_rocm_port_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     import torch
@@ -792,6 +855,19 @@ def main():
                "s_per_frame_max": round(cts_[-1], 3),
                "sample": "%d frames of the same %s %s step at %dx%d, fp32, torch CPU on %d threads (oracle/unicorn_oracle.py = the pinned port; "
                          "the reference tree itself does not exist on the GPU box)" % (ncpu, args.model, task, H, W, cores)}
+        if args.torch_rocm_port:      # context: the same port on PyTorch-ROCm's own kernels, this GPU (child process, bounded)
+            import subprocess
+            torch.cuda.synchronize()
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-rocm-port-child", "--model", args.model, "--height", str(H), "--width", str(W),
+                                     "--cpu-frames", str(args.cpu_frames)], capture_output=True, text=True, timeout=float(os.environ.get("UNI_BENCH_PORT_TIMEOUT", "900")))
+                ln = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                cpu["torch_rocm_port"] = json.loads(ln[-1]) if ln else {"error": (cp.stderr or cp.stdout)[-300:]}
+            except subprocess.TimeoutExpired:
+                cpu["torch_rocm_port"] = {"error": "timeout"}
+            if isinstance(cpu["torch_rocm_port"], dict):
+                cpu["torch_rocm_port"]["note"] = ("oracle port executed by PyTorch-ROCm eager kernels on the same MI355X (context for `value`; kind = port: the "
+                                                  "reference tree cannot travel to the GPU box)")
         if ious:
             iou = torch.cat(ious)
             parity = {"vs": "CPU oracle (fp32), %d frames of the timed stream, top-500 anchors by oracle score" % ncpu,
@@ -831,8 +907,31 @@ def main():
                 del gs
             except Exception as e:                  # noqa: BLE001 -- a margin log must not take the bench line down
                 gold["%s_%dx%d" % (gname, gh, gw)] = {"error": repr(e)[:200]}
+        # the HEADLINE size itself: vectors of the real reference at 800 x 1280 (tests/golden/make_golden.py:run_headline; the 500 best raw head rows)
+        for gname in ("unicorn_track_large", "unicorn_track_large_mask"):
+            gp = os.path.join(gdir, "%s_%dx%d.npz" % (gname, 800, 1280))
+            if not os.path.exists(gp) or (H, W) != (800, 1280):
+                continue
+            try:
+                g = np.load(gp)
+                mf = int(g["__max_full"][0])
+                gs = main_s if gname == args.model else Stream(gname, args.precision, "sot", 800, 1280, 1, dev, seed=1, corr_prec=args.corr_precision, n_frames=1)
+                with torch.no_grad():
+                    r = gs.sot_batch(gs.frames[1])
+                hh = (r["head"][0] if gs.cfg.mask else r["head"])[0].cpu()
+                top, ref = torch.from_numpy(g["head_top_idx"]), torch.from_numpy(g["head_top_rows"])
+                iou = box_iou_pairs(hh[top, :4], ref[:, :4])
+                gold["%s_800x1280" % gname] = {"box_iou_min_top200": round(float(iou[:200].min()), 6), "box_iou_min_top500": round(float(iou.min()), 6),
+                                               "embed_rel_l2": float("%.3g" % (np.linalg.norm(golden_sample(r["e_cur"], mf) - g["embed_cur"])
+                                                                               / np.linalg.norm(g["embed_cur"]))),
+                                               "coarse_maxabs": float("%.3g" % np.abs(golden_sample(r["coarse"], mf) - g["coarse"]).max())}
+                if gs is not main_s:
+                    del gs
+            except Exception as e:                  # noqa: BLE001
+                gold["%s_800x1280" % gname] = {"error": repr(e)[:200]}
         parity["golden_vs_real_reference"] = gold
-        vals = [v["box_iou_min_top200"] for v in gold.values() if "box_iou_min_top200" in v]
+        vals = [v["box_iou_min_top200"] for v in gold.values() if "box_iou_min_top200" in v] + \
+               [v["box_iou_min_top500"] for v in gold.values() if "box_iou_min_top500" in v]
         parity["golden_box_iou_min"] = min(vals) if vals else None
         parity["margin_to_bar"] = round(min([parity["box_iou_min"]] + vals) - 0.999, 6)
         torch.cuda.empty_cache()
@@ -971,6 +1070,35 @@ def main():
             configs["mot_omni_loop"]["roofline"] = ctx_roofline(ms_.model, lambda i: ms_.omni.run(ms_.frames[1 + i % 4], (1080, 1920)))
             ms_.omni.reset()
             configs["large_mot_challenge_step"]["roofline"] = ctx_roofline(ms_.model, lambda i: ms_.omni.run_batch(ms_.batches[i % 4], (H, W)))
+            # (b') tools/track.py's OWN loop: MOTEvaluator.evaluate (mot_evaluator.py:198-222) = mode="whole" -> postprocess -> native BYTETracker.update ->
+            # area / aspect filter (unicorn_amd.tracker.ByteMOTFrame).  BYTETracker's logic runs on absolute score thresholds (0.1 floor, det_thresh =
+            # track_thresh + 0.1): the synthetic heads (scores ~1e-4) get detector-like scores here by zero obj / cls prediction biases and doubled
+            # prediction weights (the same planting as tests/planted.py:confident_head; top-300 scores ~0.5 - 0.94)
+            from types import SimpleNamespace as NS_
+            from unicorn_amd.tracker import BYTETracker, ByteMOTFrame
+            Pb_ = dict(ms_.P)
+            for k_ in list(Pb_):
+                if k_.startswith("head.") and (".obj_preds" in k_ or ".cls_preds" in k_):
+                    Pb_[k_] = torch.zeros_like(Pb_[k_]) if k_.endswith(".bias") else Pb_[k_] * 2.0
+            bs_ = Stream("unicorn_track_large_mot_challenge", args.precision, "sot", H, W, 1, dev, seed=1, corr_prec=args.corr_precision, P=Pb_)
+            ob_, _ = bs_.model(bs_.frames[1])
+            scb_ = (ob_[0, :, 4] * ob_[0, :, 5]).sort(descending=True)[0]
+            byte_ = ByteMOTFrame(bs_.model, BYTETracker(NS_(track_thresh=float((scb_[149] + scb_[150]) / 2), track_buffer=30, match_thresh=0.9, mot20=False)),
+                                 (H, W), num_classes=1, confthre=float((scb_[299] + scb_[300]) / 2), nmsthre=0.7, min_box_area=100, timer=StageTimer())
+            info_b = (1080, 1920, 1, 1, "synthetic/000001.jpg")
+            ntr_ = [0]
+
+            def run_byte(i):
+                r_ = byte_.run(bs_.frames[1 + i % 4], info_b)
+                ntr_[0] = max(ntr_[0], 0 if r_ is None else len(r_[1]))
+            configs["byte_track_loop"] = staged(run_byte, byte_.t,
+                                                stream=lambda k: sum(1 for _ in byte_.run_stream((bs_.frames[1 + j % 4] for j in range(k)), info_b)),
+                                                set_timer=lambda t_: setattr(byte_, "t", t_))
+            configs["byte_track_loop"].update({"tracks_reported_max": ntr_[0], "candidates_after_conf_filter": 300,
+                                               "note": "mot_evaluator.py:198-222 (tools/track.py's loop) per frame on unicorn_track_large_mot_challenge: whole -> "
+                                                       "uni_postprocess -> native BYTETracker.update (Kalman filter, IoU + score fusion, exact assignment) -> filter; "
+                                                       "detector-like scores planted (zero obj / cls biases, prediction weights x2)"})
+            del bs_, byte_
         del ms_
         torch.cuda.empty_cache()
         with torch.no_grad():      # (c) MOTS loop (mot_evaluator.py:770-890): CondInst masks, overlap-free merge, device RLE

@@ -1052,3 +1052,54 @@ def test_bench_two_ranks_shared_gpu_mix_plumbing():
     METRICS["bench_two_ranks_shared_gpu"] = {"tasks": tasks, "gather": {k: g[k] for k in ("calls", "rows", "lost_rows", "rle_strings")},
                                               "rccl_probe": g["dist"]["rccl_probe"]}
     _dump()
+
+
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_large"])
+def test_sot_driver_vs_reference_driver_class_golden(exp, golden_dir):
+    """Drop-in evidence at the DRIVER level: tests/golden/driver_sot_*.npz hold what the reference's OWN `UnicornSOTTrack`
+    (external/lib/test/tracker/unicorn_sot.py, imported unmodified, driven like lib/test/evaluation/tracker.py:138-198: initialize, then track per
+    frame) produced with the reference's own model on the CPU (tests/golden/make_golden_drivers.py: raw uint8 RGB frames at the network size, planted
+    detector-like scores, ~21000 candidates through postprocess = the largest NMS the path can see).  `unicorn_amd.tracker.UnicornSOTTrack` + the HIP
+    model on the same frames must report the same detections (IoU > 0.999, scores within 1e-4) and the same integer `target_bbox` (+-1 px: the
+    reference truncates floats)."""
+    from planted import confident_head
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import UnicornSOTTrack
+    H, W = 800, 1280
+    g = np.load(os.path.join(golden_dir, "driver_sot_%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg))
+    m = Unicorn(exp, precision="f16x2").cuda()
+    assert not m.load_state_dict(P, strict=False)[0]
+    m.eval()
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    rng = np.random.default_rng(seed)                                  # tests/golden/make_golden_drivers.py:driver_clip
+    base = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    frames = []
+    for t in range(n + 1):
+        f = np.roll(base, (3 * t, 5 * t), (0, 1)).astype(np.int16) + rng.integers(0, 8, (H, W, 3), dtype=np.int16)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    trk = UnicornSOTTrack(m, input_size=(H, W))
+    trk.initialize(frames[0], {"init_bbox": [float(v) for v in g["init_bbox"]]})
+    cx = lambda t: torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]], 1)
+    met = []
+    for t in range(1, n + 1):
+        ref = torch.from_numpy(g["det_%d" % t])
+        cur, _ = trk._prep(frames[t])
+        det = trk.get_det_results(cur)
+        assert det is not None
+        nd = int(det.shape[0])
+        d = det[:ref.shape[0]].cpu().clone()
+        d[:, 0:4:2] = d[:, 0:4:2].clamp(min=0, max=W)
+        d[:, 1:4:2] = d[:, 1:4:2].clamp(min=0, max=H)
+        iou = box_iou_pairs(cx(d[:, :4]), cx(ref[:, :4]))
+        res = trk.track(frames[t])
+        state_ref = g["target_bbox_%d" % t]
+        met.append({"frame": t, "n_det": [nd, int(g["n_det_%d" % t][0])], "iou_min": float(iou.min()),
+                    "score_maxabs": float((d[:, 4] * d[:, 5] - ref[:, 4] * ref[:, 5]).abs().max()),
+                    "target_bbox": [[int(v) for v in res["target_bbox"]], [int(v) for v in state_ref]]})
+        assert float(iou.min()) > 0.999 and met[-1]["score_maxabs"] < 1e-4, met[-1]
+        assert abs(nd - int(g["n_det_%d" % t][0])) <= max(2, nd // 2000), met[-1]      # NMS survivors: borderline IoU pairs may flip among ~21000
+        assert max(abs(int(a) - int(b)) for a, b in zip(res["target_bbox"], state_ref)) <= 1, met[-1]
+    METRICS["driver_sot_%s" % exp] = met
+    _dump()
