@@ -272,7 +272,7 @@ def _dwln_decode(out, fmt, M, C_):
 
 @pytest.mark.parametrize("fmt", [2, 1, 0])
 @pytest.mark.parametrize("shape", [(768, 6, 49, 83), (192, 2, 101, 163), (256, 3, 57, 90), (384, 4, 50, 81), (512, 5, 33, 70), (96, 3, 20, 24),
-                                   (768, 1, 10, 10), (768, 1, 50, 80), (768, 2, 31, 45), (768, 1, 49, 83),      # row-split one-frame kernel (dwconv7_lns: <= 512 strips), odd H / ragged W / two samples
+                                   (768, 1, 10, 10), (768, 1, 50, 80), (768, 2, 31, 45), (768, 1, 45, 83), (768, 1, 49, 83),      # row-split one-frame kernel (dwconv7_lns: <= 256 strips), odd H / ragged W / two samples; 275 strips: the fallback
                                    (192, 3, 150, 323), (384, 3, 127, 163), (192, 2, 201, 320)])      # packed-lane strip groups (ragged last group, full rows)
 def test_dwconv7_ln_batched_all_formats(L, shape, fmt):
     """uni_dwconv7_ln_ex = the call the engine makes per ConvNeXt block: B stacked maps, every operand format (bf16 / fp32 / f16x2 rows),

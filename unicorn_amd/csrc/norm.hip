@@ -971,11 +971,11 @@ int launch_dwconv7_ln(const DwLnArgs& a, hipStream_t s) {
     const long n8 = (long)cdiv(a.W, 8) * a.H * nb * CG;
     int px = n8 >= 150000L ? 16 : n8 >= 70000L ? 8 : 4;
     if (env) px = atoi(env);
-    // one frame per call, C = 768: the row-split kernel (above) while the map has at most ~2 rounds of one-strip blocks; UNI_DW_SPLIT=0 = A/B switch
+    // one frame per call, C = 768: the row-split kernel (above) while the map is at most ONE round of one-strip blocks; UNI_DW_SPLIT=0 = A/B switch
     static const int split_env = getenv("UNI_DW_SPLIT") ? atoi(getenv("UNI_DW_SPLIT")) : 1;
     if (split_env && !env && a.C == 768 && (long)a.W * a.C * 4 < (1L << 30)) {
         const int spr = cdiv(a.W, 8), nst = spr * cdiv(a.H, 2) * nb;
-        if (nst <= 512) {
+        if (nst <= 256 || split_env == 2) {      // one round of blocks (242 vs 148 us at 16 frames, 31 us at two)      // (UNI_DW_SPLIT=2: every map -- the 16-frame experiment of profiles/r06_dwconv_b1_rowsplit.txt)
             constexpr int ldsb = 3 * 16 * 192 * 16 + 2 * 3 * 16 * 4;
             static DevOnce once;
             UNI_LDS_OPTIN(once, "dwconv7_lns", ldsb, reinterpret_cast<const void*>(&dwconv7_lns_kernel<768>));
