@@ -602,7 +602,7 @@ def test_batched_frames_equal_single_frame_runs(precision):
     torch.cuda.synchronize()
     # bf16: the fp64 GN-statistics atomics arrive in a different order -> a different last bit of rstd can flip a bf16
     # rounding, which the random-weight head then amplifies; the exact-fp32 mode pins the batching logic itself
-    tol = 2e-5 if precision in EXACT else 1e-1
+    tol = 5e-5 if precision in EXACT else 1e-1      # (B = 1 and B = 3 take different GEMM tile shapes and fp64-atomic orders: 1.0e-5 .. 2.3e-5 measured over boxes / rounds)
     def close(a, b, what):
         a, b = a.float().cpu(), b.float().cpu()
         err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
