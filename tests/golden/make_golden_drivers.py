@@ -1,6 +1,8 @@
 """Golden sequences from the REAL reference DRIVER classes executed end to end (run in the build container only).
 
-    python tests/golden/make_golden_drivers.py
+    python tests/golden/make_golden_drivers.py [sot] [omni]
+
+(second half, `run_omni_evaluator`: the reference's `MOTEvaluator.evaluate_omni` method itself on a stand-in dataloader -> the MOT result file it writes)
 
 `external/lib/test/tracker/unicorn_sot.py:UnicornSOTTrack` -- the class `tools/test.py unicorn_sot ...` instantiates -- is imported from
 /root/reference UNMODIFIED and driven exactly like `lib/test/evaluation/tracker.py:138-198` drives it (`initialize(image, info)`, then `track(image)`
@@ -55,16 +57,21 @@ def install_driver_patches():
         assert (img.shape[1], img.shape[0]) == tuple(size), "only the identity resize is allowed here (cv2 is absent: its arithmetic must not enter the golden)"
         return img
     cv2.cvtColor, cv2.resize = cvtColor, resize
-    torch.Tensor.cuda = lambda self, *a, **k: self
+    # a host <-> device transfer is a COPY: the reference relies on it (MOTEvaluator.convert_to_coco_format rescales `output.cpu()[:, :4]` in place,
+    # mot_evaluator.py:623-632, before the same `outputs` go to the tracker) -- no-op transfers would alias and corrupt the boxes on a CPU-only run
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()
     torch.nn.Module.cuda = lambda self, *a, **k: self
     torch.Tensor.half = lambda self: self.float()          # the fp16 casts of the propagation are dropped (fp32 statement)
     _to = torch.Tensor.to
 
     def to(self, *a, **k):
+        moved = any(isinstance(v, str) and v.startswith("cuda") for v in a) or (isinstance(k.get("device"), str) and k["device"].startswith("cuda"))
         a = tuple("cpu" if isinstance(v, str) and v.startswith("cuda") else v for v in a)
         if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
             k["device"] = "cpu"
-        return _to(self, *a, **k)
+        r = _to(self, *a, **k)
+        return r.clone() if moved and r is self else r
     torch.Tensor.to = to
     ext = os.path.join(rb.REF_ROOT, "external")
     if ext not in sys.path:
@@ -112,7 +119,72 @@ def run_sot_driver(exp_name, H, W, nframes, seed):
     np.savez_compressed(os.path.join(HERE, "driver_sot_%s_%dx%d.npz" % (exp_name, H, W)), **out)
 
 
+def run_omni_evaluator(exp_name, H, W, nframes, seed, ncand=300):
+    """`MOTEvaluator.evaluate_omni` (unicorn/evaluators/mot_evaluator.py:925-1105) -- the method `tools/track_omni.py` calls -- executed UNMODIFIED on a
+    stand-in dataloader of `nframes` frames of one video, with the reference's own model and the reference's own `QuasiDenseEmbedTracker()`; the MOT result
+    file it writes (`write_results`, :49-58) is the golden.  Substituted: `torch.cuda.FloatTensor` / `synchronize` on the CPU, `evaluate_prediction`
+    (COCOeval glue) -> None.  `confthre` is the evaluator's constructor argument (tools/track_omni.py --conf): set between two neighbouring scores of
+    the first frame so that ~`ncand` candidates pass."""
+    install_driver_patches()
+    import tempfile
+    import torch.nn.functional as F  # noqa: F401
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.synchronize = lambda *a, **k: None
+    for absent in ("mmcv", "scalabel", "scalabel.label", "scalabel.label.io", "scalabel.label.transforms", "scalabel.label.typing", "scalabel.eval",
+                   "scalabel.eval.mot", "scalabel.eval.detect", "scalabel.eval.ins_seg", "scalabel.eval.mots", "scalabel.label.to_coco"):
+        if absent not in sys.modules:          # imported by unicorn/evaluators/__init__.py through the BDD100K evaluator only (out of scope); never called here
+            sys.modules[absent] = rb._Anything.__new__(rb._Anything) if False else types.ModuleType(absent)
+    from unicorn.evaluators.mot_evaluator import MOTEvaluator
+    cfg = uo.CONFIGS[exp_name]
+    P = confident_head(synth.synth_state_dict(cfg), 0.0, 0.0, 2.0)
+    model, _ = rb.build_reference_model(exp_name)
+    missing, unexpected = model.load_state_dict(P, strict=False)
+    assert not unexpected and all("mask_head" in m for m in missing)
+    frames, _ = synth.synth_clip(H, W, nframes + 1, seed=seed)
+    with torch.no_grad():
+        o, _ = model(frames[1], mode="whole")
+    sc = (o[0, :, 4] * o[0, :, 5]).sort(descending=True)[0]
+    confthre = float((sc[ncand - 1] + sc[ncand]) / 2)
+    img_h, img_w = int(H * 1.35), int(W * 1.35)
+
+    class Loader(list):
+        dataset = types.SimpleNamespace(class_ids=[1])
+    loader = Loader()
+    for t in range(1, nframes + 1):
+        info = (torch.tensor([img_h]), torch.tensor([img_w]), torch.tensor([t]), torch.tensor([1]), ["SYN-01/img1/%06d.jpg" % t])
+        loader.append((frames[t], None, info, torch.tensor([t])))
+    ev = MOTEvaluator(types.SimpleNamespace(min_box_area=10), loader, (H, W), confthre, 0.7, 1)      # (--min_box_area 10: the synthetic heads regress small boxes)
+    ev.evaluate_prediction = lambda data_list, statistics: None
+    out_dir = tempfile.mkdtemp()
+    # observe (not alter) what the reference tracker returns per frame: the result file keeps only tracks that pass the area / aspect filter (:1069-1072)
+    import unicorn.tracker.quasi_dense_embed_tracker as qd
+    seen, orig_match = [], qd.QuasiDenseEmbedTracker.match
+
+    def tap(self, bboxes, labels, track_feats, frame_id, *a, **k):
+        r = orig_match(self, bboxes, labels, track_feats, frame_id, *a, **k)
+        seen.append((int(frame_id), r[0].detach().clone(), r[2].detach().clone()))
+        return r
+    qd.QuasiDenseEmbedTracker.match = tap
+    try:
+        ev.evaluate_omni(model, result_folder=out_dir)
+    finally:
+        qd.QuasiDenseEmbedTracker.match = orig_match
+    rows = np.loadtxt(os.path.join(out_dir, "SYN-01.txt"), delimiter=",", ndmin=2)[:, :7]      # frame, id, x1, y1, w, h, score (rounded by write_results)
+    print(exp_name, "evaluate_omni:", {int(f): int((rows[:, 0] == f).sum()) for f in np.unique(rows[:, 0])}, "confthre", confthre,
+          "match outputs per frame:", [(f, int(b.shape[0]), int((i > -1).sum())) for f, b, i in seen], flush=True)
+    out = dict(rows=rows.astype(np.float64), confthre=np.array([confthre]), seed=np.array([seed]), nframes=np.array([nframes]),
+               img_hw=np.array([img_h, img_w]), size=np.array([H, W]))
+    for f, b, i in seen:
+        out["match_bboxes_%d" % f] = b.numpy().astype(np.float32)
+        out["match_ids_%d" % f] = i.numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "driver_omni_%s_%dx%d.npz" % (exp_name, H, W)), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    run_sot_driver("unicorn_track_tiny", 800, 1280, 3, seed=21)
-    run_sot_driver("unicorn_track_large", 800, 1280, 2, seed=22)
+    which = sys.argv[1:] or ["sot", "omni"]
+    if "sot" in which:
+        run_sot_driver("unicorn_track_tiny", 800, 1280, 3, seed=21)
+        run_sot_driver("unicorn_track_large", 800, 1280, 2, seed=22)
+    if "omni" in which:
+        run_omni_evaluator("unicorn_track_large_mot_challenge", 800, 1280, 3, seed=23)

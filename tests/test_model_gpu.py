@@ -1103,3 +1103,63 @@ def test_sot_driver_vs_reference_driver_class_golden(exp, golden_dir):
         assert max(abs(int(a) - int(b)) for a, b in zip(res["target_bbox"], state_ref)) <= 1, met[-1]
     METRICS["driver_sot_%s" % exp] = met
     _dump()
+
+
+def test_omni_loop_vs_reference_evaluate_omni_method_golden(golden_dir):
+    """tests/golden/driver_omni_*.npz = what the reference's OWN `MOTEvaluator.evaluate_omni` METHOD (mot_evaluator.py:925-1105, executed unmodified on a stand-in
+    dataloader with the reference model and the reference `QuasiDenseEmbedTracker()` defaults, tests/golden/make_golden_drivers.py) wrote to its MOT result file,
+    plus the boxes / ids its tracker returned per frame.  `unicorn_amd.tracker.OmniMOTFrame` + native tracker + HIP model on the same frames: the same ~300
+    detections per frame reach the tracker (boxes within 0.05 px at the original-image scale, scores within 1e-5), the same ids come back, and the filtered, rounded
+    result rows (`:1064-1082`, `write_results` `:49-58`) are the file's."""
+    from planted import confident_head
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import OmniMOTFrame, QuasiDenseEmbedTracker
+    exp, H, W = "unicorn_track_large_mot_challenge", 800, 1280
+    g = np.load(os.path.join(golden_dir, "driver_omni_%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg), 0.0, 0.0, 2.0)
+    m = Unicorn(exp, precision="f16x2").cuda()
+    assert not m.load_state_dict(P, strict=False)[0]
+    m.eval()
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    frames, _ = synth.synth_clip(H, W, n + 1, seed=seed)
+    img_hw = tuple(int(v) for v in g["img_hw"])
+    trk = QuasiDenseEmbedTracker()                                      # the reference's defaults (evaluate_omni :968, :979)
+    seen, inner = [], trk.match
+
+    def tap(bboxes, labels, feats, frame_id, *a, **k):
+        r = inner(bboxes, labels, feats, frame_id, *a, **k)
+        seen.append((torch.as_tensor(r[0]).clone(), torch.as_tensor(r[2]).clone()))
+        return r
+    trk.match = tap
+    omni = OmniMOTFrame(m, trk, (H, W), num_classes=1, confthre=float(g["confthre"][0]), nmsthre=0.7, embed_score_thr=0.1)
+    rows, met = [], []
+    for t in range(1, n + 1):
+        with torch.no_grad():
+            out_b, out_ids = omni.run(frames[t].cuda(), img_hw)
+        b_ref, i_ref = torch.from_numpy(g["match_bboxes_%d" % t]), torch.from_numpy(g["match_ids_%d" % t])
+        b_h, i_h = seen[-1]
+        assert abs(b_h.shape[0] - b_ref.shape[0]) <= 2, (t, b_h.shape, b_ref.shape)
+        if b_h.shape[0] == b_ref.shape[0]:
+            d = (b_h[:, :4] - b_ref[:, :4]).abs().max(1)[0]
+            same_order = bool((d < 0.05).all())
+            if not same_order:      # two near-equal scores may swap rows: compare as sets
+                d = torch.stack([(b_ref[:, :4] - bh[:4]).abs().max(1)[0].min() for bh in b_h])
+            met.append({"frame": t, "n": int(b_h.shape[0]), "box_maxabs": float(d.max()), "same_order": same_order,
+                        "score_maxabs": float((b_h[:, 4] - b_ref[:, 4]).abs().max()) if same_order else None})
+            assert float(d.max()) < 0.05, met[-1]
+            if same_order:
+                assert met[-1]["score_maxabs"] < 1e-5 and torch.equal(i_h.long(), i_ref.long()), met[-1]
+        assert sorted(int(v) for v in i_ref[i_ref > -1]) == sorted(int(v) for v in torch.as_tensor(out_ids)), (t, out_ids, i_ref[i_ref > -1])
+        ob = torch.as_tensor(out_b).numpy()
+        for i in range(ob.shape[0]):                                     # evaluate_omni :1064-1082
+            x1, y1, x2, y2, score = [float(v) for v in ob[i]]
+            w, h = x2 - x1, y2 - y1
+            if w * h > 10 and not (w / h > 1.6):
+                rows.append([t, int(torch.as_tensor(out_ids)[i]) + 1, round(x1, 1), round(y1, 1), round(w, 1), round(h, 1), round(score, 2)])
+    ref_rows = g["rows"]
+    METRICS["driver_omni_%s" % exp] = {"frames": met, "result_rows": [len(rows), int(ref_rows.shape[0])]}
+    _dump()
+    assert len(rows) == ref_rows.shape[0], (rows, ref_rows)
+    rr = np.array(rows, dtype=np.float64)
+    assert np.array_equal(rr[:, :2], ref_rows[:, :2]) and np.abs(rr[:, 2:6] - ref_rows[:, 2:6]).max() <= 0.11 and np.abs(rr[:, 6] - ref_rows[:, 6]).max() <= 0.011, (rr, ref_rows)
