@@ -1,6 +1,6 @@
 """Golden sequences from the REAL reference DRIVER classes executed end to end (run in the build container only).
 
-    python tests/golden/make_golden_drivers.py [sot] [omni]
+    python tests/golden/make_golden_drivers.py [sot] [omni] [byte] [vos]
 
 (second half, `run_omni_evaluator`: the reference's `MOTEvaluator.evaluate_omni` method itself on a stand-in dataloader -> the MOT result file it writes)
 
@@ -180,9 +180,113 @@ def run_omni_evaluator(exp_name, H, W, nframes, seed, ncand=300):
     np.savez_compressed(os.path.join(HERE, "driver_omni_%s_%dx%d.npz" % (exp_name, H, W)), **out)
 
 
+def run_vos_driver(exp_name, H, W, nframes, seed):
+    """`external/lib/test/tracker/unicorn_vos.py:UnicornVOSTrack` (the class `tools/test.py unicorn_vos ...` instantiates), unmodified, K = 3 objects given in
+    the first frame: initialize, then track per frame -> the (H, W) uint8 id map of every frame (soft aggregation, :99-120) and the per-object integer box states.
+    Prediction biases are planted at -4.2 (synthetic: -4.5) so that a few hundred of the 21000 anchors pass the driver's confthre = 0.001 per object and
+    `postprocess_inst` has CondInst masks to compute (at -4.5 nothing passes; with detector-like scores all 21000 would, 86 GB of masks)."""
+    install_driver_patches()
+    from lib.test.tracker.unicorn_vos import UnicornVOSTrack
+    cfg = uo.CONFIGS[exp_name]
+    P = confident_head(synth.synth_state_dict(cfg), -4.2, -4.2)
+    ck = "/tmp/_driver_ckpt_%s.pth" % exp_name
+    ref_model, _ = rb.build_reference_model(exp_name)                  # the VOS driver loads strictly: a released checkpoint also carries the mask head's two buffers
+    bufs = {k: v.clone() for k, v in ref_model.state_dict().items() if k.startswith("head.mask_head.")}
+    del ref_model
+    torch.save({"model": dict(P, **bufs)}, ck)
+    cwd = os.getcwd()
+    os.chdir(rb.REF_ROOT)
+    try:
+        trk = UnicornVOSTrack(types.SimpleNamespace(exp_name=exp_name, checkpoint=ck), "synthetic")
+    finally:
+        os.chdir(cwd)
+    assert tuple(trk.input_size) == (H, W), trk.input_size
+    trk.device = "cpu"
+    frames = driver_clip(H, W, nframes, seed)
+    boxes = {"1": [W * 0.25, H * 0.25, W * 0.25, H * 0.25], "2": [W * 0.55, H * 0.1, W * 0.35, H * 0.35], "3": [W * 0.1, H * 0.55, W * 0.3, H * 0.4]}      # xywh
+    trk.initialize(frames[0], {"init_object_ids": list(boxes), "sequence_object_ids": list(boxes), "init_bbox": {k: list(v) for k, v in boxes.items()}})
+    out = {"seed": np.array([seed]), "size": np.array([H, W]), "nframes": np.array([nframes]), "boxes": np.array([boxes[k] for k in boxes], dtype=np.float64)}
+    for t in range(1, nframes + 1):
+        seg = trk.track(frames[t], {})["segmentation"]
+        out["seg_%d" % t] = seg.astype(np.uint8)
+        out["states_%d" % t] = np.array([trk.state_pre_dict[k] for k in boxes], dtype=np.float64)
+        print(exp_name, "vos frame", t, "pixels per id", {int(i): int((seg == i).sum()) for i in np.unique(seg)}, "states", out["states_%d" % t].tolist(), flush=True)
+    np.savez_compressed(os.path.join(HERE, "driver_vos_%s_%dx%d.npz" % (exp_name, H, W)), **out)
+
+
+def byte_clip(H, W, nframes, seed):
+    """a nearly static video: randomly initialised heads regress boxes that do not persist under the (3t, 5t) px motion of synth_clip, and an IoU tracker then
+    has nothing to associate -- frames 1 and 2 are the same image (every track re-associates: Kalman update, confirmation of the tracks born in frame 2), frame t > 2 is shifted by (t - 2) px along x"""
+    base, _ = synth.synth_clip(H, W, 2, seed=seed)
+    return [base[0]] + [torch.roll(base[1], shifts=max(t - 2, 0), dims=3).contiguous() for t in range(1, nframes + 1)]      # shifts 0, 0, 1, 2, ...
+
+
+def run_byte_evaluator(exp_name, H, W, nframes, seed, ncand=150, ntrk=120):
+    """`MOTEvaluator.evaluate` (mot_evaluator.py:100-240) -- the method `tools/track.py` calls -- executed UNMODIFIED like run_omni_evaluator, with the reference's
+    own `BYTETracker` (byte_tracker.py / matching.py / kalman_filter.py; its absent third-party solvers `lap.lapjv` / `cython_bbox.bbox_overlaps` are the
+    restatements of oracle/bytetrack_oracle.py -- declared unpinned).  `track_thresh` / `confthre` are user arguments (tools/track.py:100-108), set between
+    neighbouring scores of the first frame."""
+    install_driver_patches()
+    import tempfile
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.synchronize = lambda *a, **k: None
+    for absent in ("mmcv", "scalabel", "scalabel.label", "scalabel.label.io", "scalabel.label.transforms", "scalabel.label.typing", "scalabel.eval",
+                   "scalabel.eval.mot", "scalabel.eval.detect", "scalabel.eval.ins_seg", "scalabel.eval.mots", "scalabel.label.to_coco"):
+        if absent not in sys.modules:
+            sys.modules[absent] = types.ModuleType(absent)
+    from unicorn.evaluators.mot_evaluator import MOTEvaluator
+    import unicorn.tracker.byte_tracker as bt
+    cfg = uo.CONFIGS[exp_name]
+    P = confident_head(synth.synth_state_dict(cfg), 0.0, 0.0, 2.0)
+    model, _ = rb.build_reference_model(exp_name)
+    missing, unexpected = model.load_state_dict(P, strict=False)
+    assert not unexpected and all("mask_head" in m for m in missing)
+    frames = byte_clip(H, W, nframes, seed)
+    with torch.no_grad():
+        o, _ = model(frames[1], mode="whole")
+    sc = (o[0, :, 4] * o[0, :, 5]).sort(descending=True)[0]
+    confthre, track_thresh = float((sc[ncand - 1] + sc[ncand]) / 2), float((sc[ntrk - 1] + sc[ntrk]) / 2)
+    img_h, img_w = int(H * 1.35), int(W * 1.35)
+
+    class Loader(list):
+        dataset = types.SimpleNamespace(class_ids=[1])
+    loader = Loader()
+    for t in range(1, nframes + 1):
+        info = (torch.tensor([img_h]), torch.tensor([img_w]), torch.tensor([t]), torch.tensor([1]), ["SYN-02/img1/%06d.jpg" % t])
+        loader.append((frames[t], None, info, torch.tensor([t])))
+    args = types.SimpleNamespace(track_thresh=track_thresh, track_buffer=30, match_thresh=0.9, mot20=False, min_box_area=10)
+    ev = MOTEvaluator(args, loader, (H, W), confthre, 0.7, 1)
+    ev.evaluate_prediction = lambda data_list, statistics: None
+    out_dir = tempfile.mkdtemp()
+    seen, orig_update = [], bt.BYTETracker.update
+
+    def tap(self, output_results, img_info, img_size):
+        r = orig_update(self, output_results, img_info, img_size)
+        seen.append(np.array([[*t_.tlwh, t_.track_id, t_.score] for t_ in r], dtype=np.float64).reshape(-1, 6))
+        return r
+    bt.BYTETracker.update = tap
+    bt.BaseTrack._count = 0
+    try:
+        ev.evaluate(model, result_folder=out_dir)
+    finally:
+        bt.BYTETracker.update = orig_update
+    rows = np.loadtxt(os.path.join(out_dir, "SYN-02.txt"), delimiter=",", ndmin=2)[:, :7]
+    print(exp_name, "evaluate (ByteTrack):", {int(f): int((rows[:, 0] == f).sum()) for f in np.unique(rows[:, 0])}, "confthre", confthre, "track_thresh", track_thresh,
+          "tracks returned per frame:", [int(v.shape[0]) for v in seen], flush=True)
+    out = dict(rows=rows.astype(np.float64), confthre=np.array([confthre]), track_thresh=np.array([track_thresh]), seed=np.array([seed]), nframes=np.array([nframes]),
+               img_hw=np.array([img_h, img_w]), size=np.array([H, W]))
+    for t, v in enumerate(seen):
+        out["tracks_%d" % (t + 1)] = v
+    np.savez_compressed(os.path.join(HERE, "driver_byte_%s_%dx%d.npz" % (exp_name, H, W)), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["sot", "omni"]
+    which = sys.argv[1:] or ["sot", "omni", "byte", "vos"]
+    if "vos" in which:
+        run_vos_driver("unicorn_track_tiny_mask", 800, 1280, 2, seed=25)
+    if "byte" in which:
+        run_byte_evaluator("unicorn_track_large_mot_challenge", 800, 1280, 4, seed=24)
     if "sot" in which:
         run_sot_driver("unicorn_track_tiny", 800, 1280, 3, seed=21)
         run_sot_driver("unicorn_track_large", 800, 1280, 2, seed=22)

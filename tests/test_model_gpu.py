@@ -1163,3 +1163,101 @@ def test_omni_loop_vs_reference_evaluate_omni_method_golden(golden_dir):
     assert len(rows) == ref_rows.shape[0], (rows, ref_rows)
     rr = np.array(rows, dtype=np.float64)
     assert np.array_equal(rr[:, :2], ref_rows[:, :2]) and np.abs(rr[:, 2:6] - ref_rows[:, 2:6]).max() <= 0.11 and np.abs(rr[:, 6] - ref_rows[:, 6]).max() <= 0.011, (rr, ref_rows)
+
+
+def test_byte_loop_vs_reference_evaluate_method_golden(golden_dir):
+    """tests/golden/driver_byte_*.npz = the MOT result file of the reference's OWN `MOTEvaluator.evaluate` method (mot_evaluator.py:100-240, what `tools/track.py`
+    calls; reference model + reference `BYTETracker`, executed unmodified on a stand-in dataloader, tests/golden/make_golden_drivers.py:run_byte_evaluator) and the
+    tracks its tracker returned per frame.  `unicorn_amd.tracker.ByteMOTFrame` + the native BYTETracker + the HIP model on the same frames: same track ids per frame,
+    tlwh within 0.05 px, scores within 1e-5, and the same filtered, rounded result rows."""
+    from types import SimpleNamespace
+    from planted import confident_head
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import BYTETracker, ByteMOTFrame
+    from unicorn_amd.tracker import byte_tracker as bt
+    exp, H, W = "unicorn_track_large_mot_challenge", 800, 1280
+    g = np.load(os.path.join(golden_dir, "driver_byte_%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg), 0.0, 0.0, 2.0)
+    m = Unicorn(exp, precision="f16x2").cuda()
+    assert not m.load_state_dict(P, strict=False)[0]
+    m.eval()
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    base, _ = synth.synth_clip(H, W, 2, seed=seed)                      # make_golden_drivers.py:byte_clip
+    frames = [base[0]] + [torch.roll(base[1], shifts=max(t - 2, 0), dims=3).contiguous() for t in range(1, n + 1)]
+    info = (int(g["img_hw"][0]), int(g["img_hw"][1]), 1, 1, "SYN-02/img1/000001.jpg")
+    args = SimpleNamespace(track_thresh=float(g["track_thresh"][0]), track_buffer=30, match_thresh=0.9, mot20=False)
+    bt.clean_id()
+    trk = BYTETracker(args)
+    seen, inner = [], trk.update
+
+    def tap(*a, **k):
+        r = inner(*a, **k)
+        seen.append(np.array([[*t_.tlwh, t_.track_id, t_.score] for t_ in r], dtype=np.float64).reshape(-1, 6))
+        return r
+    trk.update = tap
+    byte = ByteMOTFrame(m, trk, (H, W), num_classes=1, confthre=float(g["confthre"][0]), nmsthre=0.7, min_box_area=10)
+    rows, met = [], []
+    for t in range(1, n + 1):
+        with torch.no_grad():
+            res = byte.run(frames[t].cuda(), info)
+        ref = g["tracks_%d" % t]
+        got = seen[-1]
+        assert got.shape == ref.shape, (t, got.shape, ref.shape)
+        o_g, o_r = np.argsort(got[:, 4], kind="stable"), np.argsort(ref[:, 4], kind="stable")
+        got, ref = got[o_g], ref[o_r]
+        met.append({"frame": t, "tracks": int(ref.shape[0]), "tlwh_maxabs": float(np.abs(got[:, :4] - ref[:, :4]).max()) if ref.size else 0.0,
+                    "score_maxabs": float(np.abs(got[:, 5] - ref[:, 5]).max()) if ref.size else 0.0})
+        assert np.array_equal(got[:, 4], ref[:, 4]), (t, got[:, 4], ref[:, 4])
+        assert met[-1]["tlwh_maxabs"] < 0.05 and met[-1]["score_maxabs"] < 1e-5, met[-1]
+        if res is not None:
+            for tlwh, tid, s_ in zip(*res):                             # write_results (:49-58)
+                rows.append([t, tid, round(float(tlwh[0]), 1), round(float(tlwh[1]), 1), round(float(tlwh[2]), 1), round(float(tlwh[3]), 1), round(float(s_), 2)])
+    ref_rows = g["rows"]
+    METRICS["driver_byte_%s" % exp] = {"frames": met, "result_rows": [len(rows), int(ref_rows.shape[0])]}
+    _dump()
+    rr = np.array(rows, dtype=np.float64).reshape(-1, 7)
+    assert rr.shape == ref_rows.shape, (rr.shape, ref_rows.shape)
+    key = lambda a: np.lexsort((a[:, 1], a[:, 0]))
+    rr, ref_rows = rr[key(rr)], ref_rows[key(ref_rows)]
+    assert np.array_equal(rr[:, :2], ref_rows[:, :2]) and np.abs(rr[:, 2:6] - ref_rows[:, 2:6]).max() <= 0.11 and np.abs(rr[:, 6] - ref_rows[:, 6]).max() <= 0.011, (rr, ref_rows)
+
+
+def test_vos_driver_vs_reference_driver_class_golden(golden_dir):
+    """tests/golden/driver_vos_*.npz = the id maps and per-object integer box states the reference's OWN `UnicornVOSTrack` class
+    (external/lib/test/tracker/unicorn_vos.py, unmodified, reference model, CPU; tests/golden/make_golden_drivers.py:run_vos_driver) produced for K = 3 objects over two
+    frames at 800 x 1280.  `unicorn_amd.tracker.UnicornVOSTrack` (one correlation + one object-batched head call per group, device-side soft aggregation) + the HIP
+    model on the same uint8 frames: the same box states (+-1 px) and the same id map up to pixels whose object probabilities tie (the synthetic mask heads put large
+    areas at p ~ 0.5; agreement is logged and held above 0.99)."""
+    from planted import confident_head
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import UnicornVOSTrack
+    exp, H, W = "unicorn_track_tiny_mask", 800, 1280
+    g = np.load(os.path.join(golden_dir, "driver_vos_%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg), -4.2, -4.2)
+    m = Unicorn(exp, precision="f16x2").cuda()
+    assert not m.load_state_dict(P, strict=False)[0]
+    m.eval()
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    rng = np.random.default_rng(seed)                                  # tests/golden/make_golden_drivers.py:driver_clip
+    base = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    frames = []
+    for t in range(n + 1):
+        f = np.roll(base, (3 * t, 5 * t), (0, 1)).astype(np.int16) + rng.integers(0, 8, (H, W, 3), dtype=np.int16)
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    ids = ["1", "2", "3"]
+    boxes = {k: [float(v) for v in g["boxes"][i]] for i, k in enumerate(ids)}
+    trk = UnicornVOSTrack(m, input_size=(H, W), d_rate=cfg.d_rate)
+    trk.initialize(frames[0], {"init_object_ids": list(ids), "sequence_object_ids": list(ids), "init_bbox": boxes})
+    met = []
+    for t in range(1, n + 1):
+        seg = trk.track(frames[t], {})["segmentation"]
+        ref = g["seg_%d" % t]
+        assert seg.shape == ref.shape and seg.dtype == np.uint8
+        states = np.array([trk.state_pre_dict[k] for k in ids], dtype=np.float64)
+        met.append({"frame": t, "agreement": float((seg == ref).mean()), "states_maxabs": float(np.abs(states - g["states_%d" % t]).max())})
+    METRICS["driver_vos_%s" % exp] = met
+    _dump()
+    for r in met:
+        assert r["states_maxabs"] <= 1.0 and r["agreement"] > 0.99, met
