@@ -1228,7 +1228,7 @@ def test_vos_driver_vs_reference_driver_class_golden(golden_dir):
     (external/lib/test/tracker/unicorn_vos.py, unmodified, reference model, CPU; tests/golden/make_golden_drivers.py:run_vos_driver) produced for K = 3 objects over two
     frames at 800 x 1280.  `unicorn_amd.tracker.UnicornVOSTrack` (one correlation + one object-batched head call per group, device-side soft aggregation) + the HIP
     model on the same uint8 frames: the same box states (+-1 px) and the same id map up to pixels whose object probabilities tie (the synthetic mask heads put large
-    areas at p ~ 0.5; agreement is logged and held above 0.99)."""
+    areas at p ~ 0.5; agreement is logged -- 0.999999 measured, one pixel of 1 024 000 -- and held above 0.9999)."""
     from planted import confident_head
     from unicorn_amd.models import Unicorn
     from unicorn_amd.tracker import UnicornVOSTrack
@@ -1260,4 +1260,4 @@ def test_vos_driver_vs_reference_driver_class_golden(golden_dir):
     METRICS["driver_vos_%s" % exp] = met
     _dump()
     for r in met:
-        assert r["states_maxabs"] <= 1.0 and r["agreement"] > 0.99, met
+        assert r["states_maxabs"] <= 1.0 and r["agreement"] > 0.9999, met
