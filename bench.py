@@ -59,9 +59,11 @@ def parse():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call leg (clean per-kernel averages under rocprofv3)")
     ap.add_argument("--with-bf16", action="store_true", help="also time the bf16 operand mode (1 MFMA per product).  Retired from the default line: it "
                     "misses the box-IoU bar with the synthetic AND the trained-like weight ensembles (profiles/r04_precision_budget_trained_like_*.json)")
-    ap.add_argument("--torch-rocm-port", action="store_true", help="also time the oracle port through PLAIN PyTorch-ROCm (eager MIOpen / rocBLAS ops, fp32 and "
-                    ".half()) on this GPU, in a child process with a timeout; reported inside cpu_baseline as context (what the hand-written path is worth "
-                    "next to the framework's own kernels) -- never `value`")
+    ap.add_argument("--no-torch-rocm-port", dest="torch_rocm_port", action="store_false", help="skip the PyTorch-ROCm port leg: by default the cpu_baseline leg also "
+                    "times the oracle port through PLAIN PyTorch-ROCm (eager MIOpen / rocBLAS ops) on this GPU, in a child process with a timeout (~20 s); reported "
+                    "inside cpu_baseline as context (what the hand-written path is worth next to the framework's own kernels) -- never `value`")
+    ap.add_argument("--torch-rocm-port", dest="torch_rocm_port", action="store_true", help=argparse.SUPPRESS)      # (round-6 scripts pass it explicitly)
+    ap.set_defaults(torch_rocm_port=True)
     ap.add_argument("--torch-rocm-port-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true", help="only rendezvous (gloo on CPU, RCCL on GPUs) and report the world size")
     return ap.parse_args()
@@ -855,12 +857,12 @@ def main():
                "s_per_frame_max": round(cts_[-1], 3),
                "sample": "%d frames of the same %s %s step at %dx%d, fp32, torch CPU on %d threads (oracle/unicorn_oracle.py = the pinned port; "
                          "the reference tree itself does not exist on the GPU box)" % (ncpu, args.model, task, H, W, cores)}
-        if args.torch_rocm_port:      # context: the same port on PyTorch-ROCm's own kernels, this GPU (child process, bounded)
+        if args.torch_rocm_port and world == 1:      # context: the same port on PyTorch-ROCm's own kernels, this GPU (child process, bounded; N = 1 only: the other ranks would wait)
             import subprocess
             torch.cuda.synchronize()
             try:
                 cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-rocm-port-child", "--model", args.model, "--height", str(H), "--width", str(W),
-                                     "--cpu-frames", str(args.cpu_frames)], capture_output=True, text=True, timeout=float(os.environ.get("UNI_BENCH_PORT_TIMEOUT", "900")))
+                                     "--cpu-frames", str(args.cpu_frames)], capture_output=True, text=True, timeout=float(os.environ.get("UNI_BENCH_PORT_TIMEOUT", "300")))
                 ln = [l for l in cp.stdout.splitlines() if l.startswith("{")]
                 cpu["torch_rocm_port"] = json.loads(ln[-1]) if ln else {"error": (cp.stderr or cp.stdout)[-300:]}
             except subprocess.TimeoutExpired:
