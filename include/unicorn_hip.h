@@ -72,6 +72,14 @@ void uni_ctx_destroy(uni_ctx* ctx);
 /* Register one reference state-dict tensor (fp32, HOST memory, reference layout e.g. OIHW).  Unknown
  * names are ignored (returns 1), like load_state_dict(strict=False). */
 int uni_ctx_load_param(uni_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* Deployment artefact for hosts without Python / torch (round 6; the role `tools/export_torchscript.py:51-71` plays for the reference: a file
+ * another runtime loads): a FLAT WEIGHTS FILE written by `unicorn_amd.utils.checkpoint.export_flat` (or tools/export_weights.py) --
+ * "UNIW1\0\0\0", the uni_model_cfg (15 int32), int32 tensor count, then per tensor: int32 name length, name bytes, int32 ndim, int64 shape[ndim],
+ * fp32 data (reference layout, little endian).  uni_weights_file_cfg reads the configuration (precision as exported; the caller may change it before
+ * uni_ctx_create), uni_ctx_load_file registers every tensor of the file like uni_ctx_load_param (call uni_ctx_finalize afterwards);
+ * *n_loaded = tensors read.  tools/capi_host_demo.cpp runs the SOT step from such a file with nothing but this header and the HIP runtime. */
+int uni_weights_file_cfg(const char* path, uni_model_cfg* cfg_out);
+int uni_ctx_load_file(uni_ctx* ctx, const char* path, int* n_loaded);
 /* Re-pack weights for the device (NHWC / [N][K] bf16, layer-scale folded).  *n_missing = parameters the
  * configured network needs but which were never loaded (left at zero). */
 int uni_ctx_finalize(uni_ctx* ctx, int* n_missing);

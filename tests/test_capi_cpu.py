@@ -209,3 +209,45 @@ def test_half_is_a_documented_no_op_that_warns_once():
         assert m.half() is m and m.half() is m
     msgs = [str(x.message) for x in w if "half()" in str(x.message)]
     assert len(msgs) == 1 and "precision='f16x2'" in msgs[0], msgs
+
+
+def test_flat_weights_file_round_trip(tmp_path):
+    """`unicorn_amd.utils.checkpoint.export_flat` / tools/export_weights.py write the deployment artefact a host without Python / torch loads through
+    uni_weights_file_cfg + uni_ctx_load_file (include/unicorn_hip.h; the role tools/export_torchscript.py:51-71 has in the reference).  CPU half: the file's header
+    is read back by the LIBRARY (no GPU needed for that entry point), every tensor by a byte-level reader; foreign keys are skipped, a missing tensor raises."""
+    import ctypes as C
+    import struct
+    import synth
+    import unicorn_oracle as uo
+    from unicorn_amd import _lib as L
+    from unicorn_amd.utils.checkpoint import export_flat, state_spec
+    exp = "unicorn_track_tiny_mask"
+    sd = synth.synth_state_dict(uo.CONFIGS[exp])
+    path = str(tmp_path / "w.uniw")
+    n = export_flat(dict(sd, **{"head.mask_head._iter": torch.zeros(1)}), exp, path, precision="fp32")      # a buffer of a released checkpoint: not in the spec, skipped
+    spec = state_spec(exp)
+    assert n == len(spec)
+    cfg = L.ModelCfg()
+    L.check(L.lib().uni_weights_file_cfg(path.encode(), C.byref(cfg)), "uni_weights_file_cfg")
+    assert list(cfg.dims) == [96, 192, 384, 768] and list(cfg.depths) == [3, 3, 9, 3] and cfg.mask == 1 and cfg.num_classes == 8 and cfg.precision == 1
+    assert cfg.embed_dim == 128 and cfg.up_rate == 4 and cfg.d_rate == 2 and cfg.n_layer_att == 3
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"UNIW1\0\0\0" and struct.unpack_from("<i", raw, 8 + 60)[0] == n
+    off, seen = 8 + 60 + 4, 0
+    while off < len(raw):
+        (nl,) = struct.unpack_from("<i", raw, off)
+        name = raw[off + 4:off + 4 + nl].decode()
+        (nd,) = struct.unpack_from("<i", raw, off + 4 + nl)
+        shape = struct.unpack_from("<%dq" % nd, raw, off + 8 + nl)
+        cnt = int(np.prod(shape)) if nd else 1
+        data = np.frombuffer(raw, dtype="<f4", count=cnt, offset=off + 8 + nl + 8 * nd)
+        assert tuple(shape) == tuple(spec[name]) and np.array_equal(data, sd[name].numpy().reshape(-1)), name
+        off += 8 + nl + 8 * nd + 4 * cnt
+        seen += 1
+    assert seen == n and off == len(raw)
+    bad = dict(sd)
+    bad.pop("bottleneck.0.weight")
+    with pytest.raises(KeyError, match="bottleneck.0.weight"):
+        export_flat(bad, exp, str(tmp_path / "bad.uniw"))
+    open(str(tmp_path / "junk.uniw"), "wb").write(b"not a weights file at all")
+    assert L.lib().uni_weights_file_cfg(str(tmp_path / "junk.uniw").encode(), C.byref(cfg)) < 0 and b"UNIW1" in L.lib().uni_last_error()

@@ -1261,3 +1261,57 @@ def test_vos_driver_vs_reference_driver_class_golden(golden_dir):
     _dump()
     for r in met:
         assert r["states_maxabs"] <= 1.0 and r["agreement"] > 0.9999, met
+
+
+def test_c_host_without_torch_matches_the_python_path(tmp_path):
+    """The drop-in boundary is a C-ABI library, not a torch extension: `tools/build/capi_host_demo` (tools/capi_host_demo.cpp: include/unicorn_hip.h + the HIP runtime,
+    nothing else -- no Python, no torch) loads a flat weights file (uni_weights_file_cfg / uni_ctx_load_file, written by unicorn_amd.utils.checkpoint.export_flat: the
+    artefact in the role of tools/export_torchscript.py:51-71), runs the SOT step of unicorn_sot.py:39-55,78-108 on two hash-pattern frames and writes the raw head rows.
+    The Python path on the same frames (weights through the same flat file, `Unicorn.load_flat_file`, and once more through load_state_dict) must give the same rows."""
+    import subprocess
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.ops import corr_softmax_pv, label_map_s8, prior_pyramid
+    from unicorn_amd.utils.checkpoint import export_flat
+    demo = os.path.join(ROOT, "tools", "build", "capi_host_demo")
+    if not os.path.exists(demo):
+        pytest.fail("tools/build/capi_host_demo is missing: run __graft_entry__.build() (csrc/build.sh builds it)")
+    exp, H, W = "unicorn_track_tiny", 320, 512
+    cfg = uo.CONFIGS[exp]
+    P = synth.synth_state_dict(cfg)
+    wfile, ofile = str(tmp_path / "tiny.uniw"), str(tmp_path / "rows.bin")
+    export_flat(P, exp, wfile)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    cp = subprocess.run([demo, wfile, str(H), str(W), ofile], capture_output=True, text=True, timeout=300, env=env)
+    assert cp.returncode == 0, (cp.stdout[-500:], cp.stderr[-1500:])
+    info = json.loads(cp.stdout.strip().splitlines()[-1])
+    rows_c = torch.from_numpy(np.fromfile(ofile, dtype=np.float32).reshape(-1, 6))
+    # the same frames in numpy: ((i + 977 t) * 2654435761 mod 2^32) >> 24
+    idx = np.arange(3 * H * W, dtype=np.uint64)
+    frame = lambda t: torch.from_numpy((((idx + np.uint64(977 * t)) * np.uint64(2654435761)) % np.uint64(1 << 32) >> np.uint64(24)).astype(np.float32)).view(1, 3, H, W)
+    box = torch.tensor([W * 0.25, H * 0.25, W * 0.5, H * 0.5])
+
+    def python_rows(m):
+        with torch.no_grad():
+            _, d_pre = m(imgs=frame(0).cuda(), mode="backbone")
+            lbs = label_map_s8(box, H, W, "cuda")
+            fpn, d_cur = m(imgs=frame(1).cuda(), mode="backbone")
+            f_pre, f_cur = m(seq_dict0=d_pre, seq_dict1=d_cur, mode="interaction")
+            e_pre, e_cur = m(feat=f_pre, mode="upsample"), m(feat=f_cur, mode="upsample")
+            pred = corr_softmax_pv(e_pre.flatten(-2).squeeze(0), e_cur.flatten(-2).squeeze(0), lbs)
+            coarse = pred.view(1, -1, d_cur["h"] * 2, d_cur["w"] * 2)
+            return m.head(fpn, prior_pyramid(coarse), mode="sot")[0].cpu()
+    m1 = Unicorn(exp, precision="f16x2").cuda()
+    assert m1.load_flat_file(wfile) == info["tensors_loaded"]
+    rows_f = python_rows(m1)
+    m2 = Unicorn(exp, precision="f16x2").cuda()
+    m2.load_state_dict(P)
+    rows_s = python_rows(m2)
+    assert rows_c.shape == rows_f.shape == rows_s.shape and info["anchors"] == rows_c.shape[0]
+    scale = float(rows_s.abs().max())
+    err_c, err_f = float((rows_c - rows_s).abs().max()) / scale, float((rows_f - rows_s).abs().max()) / scale
+    METRICS["c_host_without_torch"] = {"rows": int(rows_c.shape[0]), "max_rel_diff_c_host_vs_python": err_c, "max_rel_diff_flat_file_vs_state_dict": err_f,
+                                       "best_anchor": info["best_anchor"], "demo_stdout": info}
+    _dump()
+    # same kernels, same weights: only the fp64-atomic order of the GroupNorm sums may differ between runs
+    assert err_c < 2e-5 and err_f < 2e-5, (err_c, err_f)
+    assert int(torch.argmax(rows_s[:, 4] * rows_s[:, 5])) == info["best_anchor"]

@@ -22,6 +22,8 @@ PROTOS = {
     "uni_ctx_create": (C.c_void_p, [c_i, C.POINTER(ModelCfg)]),
     "uni_ctx_destroy": (None, [C.c_void_p]),
     "uni_ctx_load_param": (c_i, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), c_i]),
+    "uni_weights_file_cfg": (c_i, [C.c_char_p, C.POINTER(ModelCfg)]),
+    "uni_ctx_load_file": (c_i, [C.c_void_p, C.c_char_p, C.POINTER(c_i)]),
     "uni_ctx_finalize": (c_i, [C.c_void_p, C.POINTER(c_i)]),
     "uni_ctx_missing_name": (C.c_char_p, [C.c_void_p, c_i]),
     "uni_ctx_reserve": (c_i, [C.c_void_p, c_i, c_i, c_i]),

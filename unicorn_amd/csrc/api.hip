@@ -60,6 +60,75 @@ int uni_ctx_load_param(uni_ctx* ctx, const char* name, const float* host_data, c
     ctx->host[name] = std::move(p);
     return 0;
 }
+// ---- flat weights file (include/unicorn_hip.h: "UNIW1", cfg, tensors) ----
+namespace {
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+bool read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
+int open_weights(const char* path, FILE** out, uni_model_cfg* cfg, int32_t* count) {
+    UNI_REQUIRE(path, "weights file: NULL path");
+    FILE* f = fopen(path, "rb");
+    UNI_REQUIRE(f, "weights file: cannot open %s", path);
+    char magic[8];
+    int32_t raw[15];
+    if (!read_exact(f, magic, 8) || memcmp(magic, "UNIW1\0\0\0", 8) != 0 || !read_exact(f, raw, sizeof(raw)) || !read_exact(f, count, 4) || *count < 0) {
+        fclose(f);
+        uni_set_error("weights file %s: bad header (not a UNIW1 file)", path);
+        return -1;
+    }
+    static_assert(sizeof(uni_model_cfg) == 15 * sizeof(int32_t), "uni_model_cfg is 15 int32");
+    memcpy(cfg, raw, sizeof(raw));
+    *out = f;
+    return 0;
+}
+}  // namespace
+int uni_weights_file_cfg(const char* path, uni_model_cfg* cfg_out) {
+    UNI_REQUIRE(cfg_out, "weights_file_cfg: NULL cfg");
+    FILE* f = nullptr;
+    int32_t count = 0;
+    int rc = open_weights(path, &f, cfg_out, &count);
+    if (rc) return rc;
+    fclose(f);
+    return 0;
+}
+int uni_ctx_load_file(uni_ctx* ctx, const char* path, int* n_loaded) {
+    UNI_REQUIRE(ctx, "load_file: NULL ctx");
+    UNI_REQUIRE(!ctx->finalized, "load_file after finalize");
+    FILE* f = nullptr;
+    uni_model_cfg cfg;
+    int32_t count = 0;
+    int rc = open_weights(path, &f, &cfg, &count);
+    if (rc) return rc;
+    FileCloser closer{f};
+    for (int i = 0; i < 15; ++i)
+        if (i != 14 && reinterpret_cast<const int32_t*>(&cfg)[i] != reinterpret_cast<const int32_t*>(&ctx->cfg)[i]) {      // (precision may differ: the file holds fp32 tensors)
+            uni_set_error("weights file %s was exported for another network configuration (field %d: %d, context: %d)", path, i,
+                          reinterpret_cast<const int32_t*>(&cfg)[i], reinterpret_cast<const int32_t*>(&ctx->cfg)[i]);
+            return -1;
+        }
+    std::vector<char> name;
+    std::vector<float> data;
+    for (int32_t t = 0; t < count; ++t) {
+        int32_t nl = 0, nd = 0;
+        int64_t shape[8];
+        if (!read_exact(f, &nl, 4) || nl <= 0 || nl > 4096) { uni_set_error("weights file %s: truncated at tensor %d", path, t); return -1; }
+        name.assign((size_t)nl + 1, 0);
+        if (!read_exact(f, name.data(), (size_t)nl) || !read_exact(f, &nd, 4) || nd < 0 || nd > 8 || !read_exact(f, shape, sizeof(int64_t) * (size_t)nd)) {
+            uni_set_error("weights file %s: truncated at tensor %d", path, t);
+            return -1;
+        }
+        size_t n = 1;
+        for (int i = 0; i < nd; ++i) {
+            if (shape[i] < 0 || shape[i] > (1 << 28)) { uni_set_error("weights file %s: bad shape of %s", path, name.data()); return -1; }
+            n *= (size_t)shape[i];
+        }
+        data.resize(n);
+        if (!read_exact(f, data.data(), n * sizeof(float))) { uni_set_error("weights file %s: truncated data of %s", path, name.data()); return -1; }
+        rc = uni_ctx_load_param(ctx, name.data(), data.data(), shape, nd);
+        if (rc < 0) return rc;
+    }
+    if (n_loaded) *n_loaded = count;
+    return 0;
+}
 int uni_ctx_finalize(uni_ctx* ctx, int* n_missing) {
     UNI_REQUIRE(ctx, "ctx is NULL");
     UNI_REQUIRE(!ctx->finalized, "already finalized");

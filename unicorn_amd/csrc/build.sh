@@ -47,3 +47,8 @@ for probe in feed_probe persist_probe winograd_probe; do      # persist_probe: k
     hipcc --offload-arch=gfx950 -O3 -Wno-unused-value ../../tools/$probe.hip -o ../../tools/build/$probe || echo "$probe skipped (does not build here)"
   fi
 done
+# a host without Python / torch (tools/capi_host_demo.cpp: the SOT step through include/unicorn_hip.h + the HIP runtime only), non-fatal like the probes
+if [ ! -f ../../tools/build/capi_host_demo ] || [ ../../tools/capi_host_demo.cpp -nt ../../tools/build/capi_host_demo ] || [ ../../include/unicorn_hip.h -nt ../../tools/build/capi_host_demo ]; then
+  hipcc -O2 -std=c++17 ../../tools/capi_host_demo.cpp -L$OUT -lunicorn_hip -Wl,-rpath,'$ORIGIN/../../unicorn_amd/lib' -o ../../tools/build/capi_host_demo || echo "capi_host_demo skipped (does not build here)"
+fi
+

@@ -9,6 +9,7 @@ Tensors returned to the caller are ordinary torch tensors of the reference's NCH
 is channels_last (NHWC), which is what the HIP kernels produce/consume, so round trips are copy-free.
 """
 import ctypes as C
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -260,6 +261,22 @@ class Unicorn(torch.nn.Module):
             return res
         self._load(state_dict)
         return res
+
+    def load_flat_file(self, path):
+        """weights from a flat file written by `unicorn_amd.utils.checkpoint.export_flat` (uni_ctx_load_file: the path a host without torch takes); the file's
+        network configuration must be this model's"""
+        if self._ready:
+            raise L.UnicornHipError("weights already loaded (the packed device copy is immutable)")
+        if self._ctx is None:
+            raise L.UnicornHipError("call model.cuda() first (unicorn_amd has no CPU path)")
+        lib = L.lib()
+        n = C.c_int(0)
+        L.check(lib.uni_ctx_load_file(self._ctx, os.fsencode(path), C.byref(n)), "uni_ctx_load_file")
+        nm = C.c_int(0)
+        L.check(lib.uni_ctx_finalize(self._ctx, C.byref(nm)), "uni_ctx_finalize")
+        self._engine_missing = [lib.uni_ctx_missing_name(self._ctx, i).decode() for i in range(nm.value)]
+        self._ready = True
+        return n.value
 
     def _check_keys(self, state_dict, strict):
         """missing / unexpected keys against the reference model's parameter spec; a tensor whose SHAPE differs raises like

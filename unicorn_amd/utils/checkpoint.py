@@ -172,3 +172,45 @@ def remap_coco_pretrain(state_dict, num_classes, unshared_obj=True, unshared_reg
         else:
             out[k] = v
     return out
+
+
+def export_flat(state_dict, model_or_cfg, path, precision="f16x2"):
+    """Flat weights file for hosts without Python / torch (include/unicorn_hip.h: uni_weights_file_cfg / uni_ctx_load_file) -- the deployment artefact of this
+    backend, in the role `tools/export_torchscript.py:51-71` has in the reference (a file another runtime loads).  Layout: b"UNIW1\0\0\0", the uni_model_cfg as 15
+    int32, int32 tensor count, then per learnable tensor of the experiment's spec (reference names, reference layout): int32 name length, name, int32 ndim,
+    int64 shape[ndim], fp32 data.  `model_or_cfg`: an experiment name ("unicorn_track_large"), a config dict or a `unicorn_amd.models.Unicorn` instance.
+    Only tensors of the spec are written (buffers / foreign keys are skipped like load_state_dict(strict=False) ignores them); a spec tensor missing from the
+    state dict raises.  -> number of tensors written."""
+    import struct
+    import numpy as np
+    from ..models.unicorn import MODEL_CONFIGS, PRECISIONS
+    if hasattr(model_or_cfg, "dims") and hasattr(model_or_cfg, "depths") and not isinstance(model_or_cfg, dict):
+        m = model_or_cfg
+        cfg = dict(dims=m.dims, depths=m.depths, num_classes=m.num_classes, mask=m.mask, n_layer_att=m.n_layer_att, embed_dim=m.embed_dim, d_rate=m.d_rate)
+    else:
+        cfg = dict(MODEL_CONFIGS[model_or_cfg]) if isinstance(model_or_cfg, str) else dict(model_or_cfg)
+    d_rate = int(cfg.get("d_rate", 2))
+    full = dict(dims=tuple(cfg["dims"]), depths=tuple(cfg["depths"]), num_classes=int(cfg["num_classes"]), mask=bool(cfg["mask"]),
+                n_layer_att=int(cfg.get("n_layer_att", 3)), embed_dim=int(cfg.get("embed_dim", 128)), up_rate=8 // d_rate)
+    spec = state_spec(full)
+    missing = [k for k in spec if k not in state_dict]
+    if missing:
+        raise KeyError("export_flat: %d tensors of the experiment are not in the state dict, e.g. %s" % (len(missing), missing[:4]))
+    head = struct.pack("<15i", *full["dims"], *full["depths"], full["num_classes"], int(full["mask"]), full["n_layer_att"], full["embed_dim"], full["up_rate"], d_rate,
+                       PRECISIONS[precision])
+    with open(path, "wb") as f:
+        f.write(b"UNIW1\0\0\0")
+        f.write(head)
+        f.write(struct.pack("<i", len(spec)))
+        for k, shp in spec.items():
+            a = np.ascontiguousarray(state_dict[k].detach().float().cpu().numpy(), dtype="<f4")
+            if tuple(a.shape) != tuple(shp):
+                raise ValueError("export_flat: %s has shape %s, the experiment expects %s" % (k, tuple(a.shape), tuple(shp)))
+            kb = k.encode()
+            f.write(struct.pack("<i", len(kb)))
+            f.write(kb)
+            f.write(struct.pack("<i", a.ndim))
+            f.write(struct.pack("<%dq" % a.ndim, *a.shape))
+            f.write(a.tobytes())
+    return len(spec)
+
