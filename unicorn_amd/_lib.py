@@ -125,7 +125,7 @@ def verify_manifest(lib_name):
         src = os.path.join(inc if name.startswith("unicorn_") and name.endswith(".h") else csrc, name)
         if not os.path.exists(src) or sha(src) != digest:
             return fail("%s changed since %s was built (stale library)" % (name, lib_name))
-    have = {f for f in os.listdir(csrc) if f.endswith(".h")} | {f for f in os.listdir(inc) if f.endswith(".h")}
+    have = {f for f in os.listdir(csrc) if f.endswith(".h")} | ({f for f in os.listdir(inc) if f.endswith(".h")} if os.path.isdir(inc) else set())
     new = sorted(have - set(man.get("sources", {})))
     if new:
         return fail("header(s) %s are newer than the build manifest" % ", ".join(new))
