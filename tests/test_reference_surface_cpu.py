@@ -171,3 +171,33 @@ print("MODULE_SURFACE_OK")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "MODULE_SURFACE_OK" in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.skipif(not rb.reference_available(), reason="reference tree absent")
+def test_tracker_call_signatures_match_reference():
+    """`unicorn.tracker` API kept: constructor and call signatures of the two association classes the evaluators drive
+    (mot_evaluator.py:145,212 `BYTETracker(args).update(outputs[0], info_imgs, img_size)`; :968,1045 `QuasiDenseEmbedTracker().match(bboxes, labels, feats, frame_id)`),
+    and the attributes read from the tracks `update` returns (:214-222)."""
+    import inspect
+    from types import SimpleNamespace
+    rb.boot()
+    from unicorn.tracker.byte_tracker import BYTETracker as RefByte, STrack as RefSTrack
+    from unicorn.tracker.quasi_dense_embed_tracker import QuasiDenseEmbedTracker as RefQD
+    from unicorn_amd.tracker import BYTETracker, QuasiDenseEmbedTracker
+    from unicorn_amd.tracker.byte_tracker import STrack
+
+    def names(fn):
+        return [p for p in inspect.signature(fn).parameters if p != "self"]
+    assert names(BYTETracker.__init__) == names(RefByte.__init__) == ["args", "frame_rate"]
+    assert names(BYTETracker.update) == names(RefByte.update) == ["output_results", "img_info", "img_size"]
+    ref_init, our_init = inspect.signature(RefQD.__init__).parameters, inspect.signature(QuasiDenseEmbedTracker.__init__).parameters
+    assert list(ref_init) == list(our_init)
+    for k in ref_init:
+        if k != "self":
+            assert ref_init[k].default == our_init[k].default, k                 # evaluate_omni constructs the tracker with its DEFAULTS
+    assert names(QuasiDenseEmbedTracker.match)[:4] == names(RefQD.match)[:4] == ["bboxes", "labels", "track_feats", "frame_id"]
+    for attr in ("tlwh", "track_id", "score", "tlbr"):
+        assert hasattr(RefSTrack, attr) or attr in ("track_id", "score")
+        assert attr in STrack.__slots__ or hasattr(STrack, attr), attr
+    t = BYTETracker(SimpleNamespace(track_thresh=0.5, track_buffer=30, match_thresh=0.8, mot20=False))
+    assert t.update(__import__("numpy").zeros((0, 5), dtype="float32"), (100, 100), (100, 100)) == []
