@@ -42,7 +42,7 @@ EOF
 # standalone measurement program (tools/feed_probe.hip: which path feeds a CU; profiles/r05_feed_probe.txt) -- not part of the library:
 # built last and non-fatally (a probe that does not compile on another ROCm must not leave the libraries unbuilt)
 mkdir -p ../../tools/build
-for probe in feed_probe persist_probe winograd_probe; do      # persist_probe: kernel boundary vs grid barrier; winograd_probe: F(2x2,3x3) transform passes (profiles/r06_*)
+for probe in feed_probe persist_probe winograd_probe handoff_probe; do      # persist_probe: kernel boundary vs grid barrier; winograd_probe: F(2x2,3x3) transform passes (profiles/r06_*)
   if [ ! -f ../../tools/build/$probe ] || [ ../../tools/$probe.hip -nt ../../tools/build/$probe ]; then
     hipcc --offload-arch=gfx950 -O3 -Wno-unused-value ../../tools/$probe.hip -o ../../tools/build/$probe || echo "$probe skipped (does not build here)"
   fi
