@@ -237,3 +237,104 @@ def test_label_map_matches_reference_function(golden_dir):
         for b, ref in zip(g["boxes"], g["lbs_" + tag]):
             got = uo.label_map_s8(torch.from_numpy(b), H, W)[0].numpy()
             assert np.array_equal(got, ref), (tag, b)
+
+
+def test_oracle_loops_match_the_reference_evaluator_methods(golden_dir):
+    """The per-frame ORACLE loops the GPU tests lean on (uo.mot_whole -> uo.postprocess -> interaction / upsample / instance embeddings -> assoc_oracle.qd_match, and
+    -> bytetrack_oracle.byte_update) against what the reference's OWN evaluator METHODS produced end to end (tests/golden/make_golden_drivers.py: `MOTEvaluator.evaluate_omni`
+    and `MOTEvaluator.evaluate`, unmodified, reference model + reference trackers): the tracker outputs per frame and the rows of the MOT result files.  CPU, large model at
+    800 x 1280 (~40 s)."""
+    import copy
+    import assoc_oracle as ao
+    import bytetrack_oracle as bo
+    from planted import confident_head
+    torch.set_num_threads(8)
+    exp, H, W = "unicorn_track_large_mot_challenge", 800, 1280
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg), 0.0, 0.0, 2.0)
+    # ---- evaluate_omni (mot_evaluator.py:925-1105)
+    g = np.load(os.path.join(golden_dir, "driver_omni_%s_%dx%d.npz" % (exp, H, W)))
+    n, seed, conf = int(g["nframes"][0]), int(g["seed"][0]), float(g["confthre"][0])
+    frames, _ = synth.synth_clip(H, W, n + 1, seed=seed)
+    img_h, img_w = (int(v) for v in g["img_hw"])
+    scale = min(H / float(img_h), W / float(img_w))
+    st, pre, rows = ao.QDState(), None, []                               # QuasiDenseEmbedTracker() defaults
+    for t in range(1, n + 1):
+        with torch.no_grad():
+            o, d, _ = uo.mot_whole(P, cfg, frames[t])
+            det = uo.postprocess(o.clone(), 1, conf, 0.7)[0]
+            bb, sc = det[:, :4], det[:, 4:5] * det[:, 5:6]
+            keep = sc[:, 0] > 0.1
+            bb, sc = bb[keep], sc[keep]
+            if t == 1:
+                pre = copy.deepcopy(d)
+            _, fo = uo.forward_interaction(P, pre, d)
+            e = uo.forward_upsample(P, fo)
+            pre = copy.deepcopy(d)
+            emb = uo.sample_instance_embeddings(e, bb)
+        b_o, _, ids_o, _ = ao.qd_match(st, torch.cat((bb / scale, sc), 1), torch.ones((bb.shape[0],)), emb, t)
+        b_ref, i_ref = torch.from_numpy(g["match_bboxes_%d" % t]), torch.from_numpy(g["match_ids_%d" % t])
+        assert b_o.shape == b_ref.shape and (torch.as_tensor(b_o) - b_ref).abs().max() < 1e-3 and torch.equal(torch.as_tensor(ids_o).long(), i_ref.long()), t
+        ids_o = torch.as_tensor(ids_o).long()
+        v = ids_o > -1
+        ob, oi = torch.as_tensor(b_o)[v], ids_o[v]
+        order = torch.argsort(oi)
+        for i in order.tolist():
+            x1, y1, x2, y2, s_ = [float(x) for x in ob[i]]
+            w, h = x2 - x1, y2 - y1
+            if w * h > 10 and not (w / h > 1.6):
+                rows.append([t, int(oi[i]) + 1, round(x1, 1), round(y1, 1), round(w, 1), round(h, 1), round(s_, 2)])
+    rr = np.array(rows, dtype=np.float64).reshape(-1, 7)
+    assert rr.shape == g["rows"].shape and np.array_equal(rr[:, :2], g["rows"][:, :2]) and np.abs(rr[:, 2:] - g["rows"][:, 2:]).max() <= 0.11
+    # ---- evaluate (mot_evaluator.py:100-240): ByteTrack
+    g = np.load(os.path.join(golden_dir, "driver_byte_%s_%dx%d.npz" % (exp, H, W)))
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    base, _ = synth.synth_clip(H, W, 2, seed=seed)
+    frames = [base[0]] + [torch.roll(base[1], shifts=max(t - 2, 0), dims=3).contiguous() for t in range(1, n + 1)]
+    info = (int(g["img_hw"][0]), int(g["img_hw"][1]))
+    bs_ = bo.ByteState(track_thresh=float(g["track_thresh"][0]), track_buffer=30, match_thresh=0.9, mot20=False, frame_rate=30)
+    for t in range(1, n + 1):
+        with torch.no_grad():
+            o, _, _ = uo.mot_whole(P, cfg, frames[t])
+            det = uo.postprocess(o.clone(), 1, float(g["confthre"][0]), 0.7)[0]
+        tr = bo.byte_update(bs_, det.numpy(), info, (H, W))
+        got = np.array([[*x.tlwh, x.track_id, x.score] for x in tr], dtype=np.float64).reshape(-1, 6)
+        ref = g["tracks_%d" % t]
+        assert got.shape == ref.shape, (t, got.shape, ref.shape)
+        got, ref = got[np.argsort(got[:, 4], kind="stable")], ref[np.argsort(ref[:, 4], kind="stable")]
+        assert np.array_equal(got[:, 4], ref[:, 4]) and np.abs(got[:, :4] - ref[:, :4]).max() < 1e-3 and np.abs(got[:, 5] - ref[:, 5]).max() < 1e-6, t
+
+
+@pytest.mark.parametrize("exp", ["unicorn_track_tiny", "unicorn_track_large"])
+def test_oracle_sot_driver_matches_the_reference_driver_class(exp, golden_dir):
+    """uo.sot_init / sot_step / postprocess / sot_pick_box (the oracle's restatement of unicorn_sot.py:39-108) against what the reference's OWN `UnicornSOTTrack` class
+    produced end to end (tests/golden/driver_sot_*_800x1280.npz: raw uint8 frames at the network size, planted scores, ~21000 NMS candidates): the first
+    detections per frame and the integer `target_bbox` states.  CPU, tiny (3 frames) and large (2 frames)."""
+    from planted import confident_head
+    torch.set_num_threads(8)
+    H, W = 800, 1280
+    g = np.load(os.path.join(golden_dir, "driver_sot_%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg))
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    rng = np.random.default_rng(seed)                                  # make_golden_drivers.py:driver_clip; PreprocessorX: RGB -> BGR, r = 1
+    base = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    frames = []
+    for t in range(n + 1):
+        f = np.roll(base, (3 * t, 5 * t), (0, 1)).astype(np.int16) + rng.integers(0, 8, (H, W, 3), dtype=np.int16)
+        f = np.clip(f, 0, 255).astype(np.uint8)[:, :, ::-1]
+        frames.append(torch.from_numpy(np.ascontiguousarray(f.transpose(2, 0, 1))).float()[None])
+    ib = torch.tensor([float(v) for v in g["init_bbox"]])
+    box = torch.cat((ib[:2], ib[:2] + ib[2:]))
+    with torch.no_grad():
+        st = uo.sot_init(P, cfg, frames[0], box)
+        for t in range(1, n + 1):
+            r = uo.sot_step(P, cfg, st, frames[t])
+            det = uo.postprocess(r["head"].clone(), 1, 0.001, 0.65)[0]
+            ref = torch.from_numpy(g["det_%d" % t])
+            assert abs(det.shape[0] - int(g["n_det_%d" % t][0])) == 0, (t, det.shape[0], int(g["n_det_%d" % t][0]))
+            d = det[:ref.shape[0]].clone()
+            d[:, 0:4:2] = d[:, 0:4:2].clamp(min=0, max=W)
+            d[:, 1:4:2] = d[:, 1:4:2].clamp(min=0, max=H)
+            assert (d[:, :4] - ref[:, :4]).abs().max() < 1e-3 and (d[:, 4:6] - ref[:, 4:6]).abs().max() < 1e-6, t
+            assert uo.sot_pick_box(det, H, W) == [int(v) for v in g["target_bbox_%d" % t]], t
