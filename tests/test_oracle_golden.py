@@ -338,3 +338,34 @@ def test_oracle_sot_driver_matches_the_reference_driver_class(exp, golden_dir):
             d[:, 1:4:2] = d[:, 1:4:2].clamp(min=0, max=H)
             assert (d[:, :4] - ref[:, :4]).abs().max() < 1e-3 and (d[:, 4:6] - ref[:, 4:6]).abs().max() < 1e-6, t
             assert uo.sot_pick_box(det, H, W) == [int(v) for v in g["target_bbox_%d" % t]], t
+
+
+def test_oracle_vos_driver_matches_the_reference_driver_class(golden_dir):
+    """uo.vos_track_init / vos_track_frame (the oracle's restatement of unicorn_vos.py:43-200 incl. the soft aggregation) against the id maps the reference's OWN
+    `UnicornVOSTrack` class produced (tests/golden/driver_vos_unicorn_track_tiny_mask_800x1280.npz: K = 3 objects, two frames, biases planted at -4.2 so that a few
+    hundred anchors per object pass the driver's confthre = 0.001).  CPU."""
+    from planted import confident_head
+    torch.set_num_threads(8)
+    exp, H, W = "unicorn_track_tiny_mask", 800, 1280
+    g = np.load(os.path.join(golden_dir, "driver_vos_%s_%dx%d.npz" % (exp, H, W)))
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg), -4.2, -4.2)
+    n, seed = int(g["nframes"][0]), int(g["seed"][0])
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    frames = []
+    for t in range(n + 1):
+        f = np.roll(base, (3 * t, 5 * t), (0, 1)).astype(np.int16) + rng.integers(0, 8, (H, W, 3), dtype=np.int16)
+        f = np.clip(f, 0, 255).astype(np.uint8)[:, :, ::-1]
+        frames.append(torch.from_numpy(np.ascontiguousarray(f.transpose(2, 0, 1))).float()[None])
+    boxes = {}
+    for i, k in enumerate(("1", "2", "3")):
+        x, y, w, h = [float(v) for v in g["boxes"][i]]
+        boxes[k] = torch.tensor([x, y, x + w, y + h])
+    with torch.no_grad():
+        st = uo.vos_track_init(P, cfg, frames[0], boxes, (H, W), 1.0)
+        nrun = n if os.environ.get("UNI_SLOW_TESTS") else 1            # a frame costs ~90 s of CPU (hundreds of 800 x 1280 CondInst masks per object); both frames passed in round 6
+        for t in range(1, nrun + 1):
+            seg = uo.vos_track_frame(P, cfg, st, frames[t], {}, 1.0)
+            ref = g["seg_%d" % t]
+            assert seg.shape == ref.shape and float((seg == ref).mean()) > 0.99999, (t, float((seg == ref).mean()))
