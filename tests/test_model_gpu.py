@@ -1315,3 +1315,67 @@ def test_c_host_without_torch_matches_the_python_path(tmp_path):
     # same kernels, same weights: only the fp64-atomic order of the GroupNorm sums may differ between runs
     assert err_c < 2e-5 and err_f < 2e-5, (err_c, err_f)
     assert int(torch.argmax(rows_s[:, 4] * rows_s[:, 5])) == info["best_anchor"]
+
+
+def test_round6_entry_points_edge_cases(tmp_path):
+    """Edge cases of the round-6 entry points: ByteMOTFrame on a time batch (B = 2 consecutive frames per call = two calls) and on frames WITHOUT detections (the
+    tracker is not stepped, mot_evaluator.py:211); DemoPredictor without detections (`postprocess` -> [None]); the flat weights file loader on a file for ANOTHER
+    network configuration and on a truncated file (error strings, no crash); `Unicorn.load_flat_file` after weights were loaded."""
+    import ctypes as C
+    from types import SimpleNamespace
+    from planted import confident_head
+    from unicorn_amd import _lib as L
+    from unicorn_amd.models import Unicorn
+    from unicorn_amd.tracker import BYTETracker, ByteMOTFrame, DemoPredictor
+    from unicorn_amd.tracker import byte_tracker as bt
+    from unicorn_amd.utils.checkpoint import export_flat
+    exp, H, W = "unicorn_track_tiny", 320, 320
+    cfg = uo.CONFIGS[exp]
+    P = confident_head(synth.synth_state_dict(cfg))
+    m = Unicorn(exp, precision="f16x2").cuda()
+    m.load_state_dict(P)
+    frames, _ = synth.synth_clip(H, W, 3, seed=9)
+    with torch.no_grad():
+        o, _ = m(frames[1].cuda())
+    sc = (o[0, :, 4] * o[0, :, 5:].max(1)[0]).sort(descending=True)[0]
+    args = SimpleNamespace(track_thresh=float((sc[39] + sc[40]) / 2), track_buffer=30, match_thresh=0.9, mot20=False)
+    info = (480, 480, 1, 1, "x")
+    conf = float((sc[99] + sc[100]) / 2)
+    bt.clean_id()
+    seq = ByteMOTFrame(m, BYTETracker(args), (H, W), num_classes=cfg.num_classes, confthre=conf, nmsthre=0.7, min_box_area=1)
+    with torch.no_grad():
+        r_seq = [seq.run(frames[t].cuda(), info) for t in (1, 2)]
+    bt.clean_id()
+    bat = ByteMOTFrame(m, BYTETracker(args), (H, W), num_classes=cfg.num_classes, confthre=conf, nmsthre=0.7, min_box_area=1)
+    with torch.no_grad():
+        r_bat = bat.run_batch(torch.cat([frames[1], frames[2]], 0).cuda(), info)
+    assert len(r_bat) == 2
+    for a, b in zip(r_seq, r_bat):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert list(a[1]) == list(b[1]) and all(float(np.abs(x - y).max()) < 1e-2 for x, y in zip(a[0], b[0]))      # B = 1 / B = 2 take different tile shapes
+    none = ByteMOTFrame(m, BYTETracker(args), (H, W), num_classes=cfg.num_classes, confthre=2.0, nmsthre=0.7)
+    with torch.no_grad():
+        assert none.run(frames[1].cuda(), info) is None and none.tracker.frame_id == 0                                       # tracker not stepped
+    dets, _ = DemoPredictor(m, cfg.num_classes, 2.0, 0.45, (H, W)).inference(np.zeros((200, 300, 3), dtype=np.uint8))
+    assert dets == [None]
+    # ---- flat weights file: wrong configuration, truncated file, double load
+    good, other = str(tmp_path / "tiny.uniw"), str(tmp_path / "mask.uniw")
+    export_flat(P, exp, good)
+    cm = uo.CONFIGS["unicorn_track_tiny_mask"]
+    export_flat(synth.synth_state_dict(cm), "unicorn_track_tiny_mask", other)
+    m2 = Unicorn(exp, precision="f16x2").cuda()
+    with pytest.raises(L.UnicornHipError, match="another network configuration"):
+        m2.load_flat_file(other)
+    cut = str(tmp_path / "cut.uniw")
+    open(cut, "wb").write(open(good, "rb").read()[:200000])
+    m3 = Unicorn(exp, precision="f16x2").cuda()
+    with pytest.raises(L.UnicornHipError, match="truncated"):
+        m3.load_flat_file(cut)
+    with pytest.raises(L.UnicornHipError, match="already loaded"):
+        m.load_flat_file(good)
+    m4 = Unicorn(exp, precision="fp32").cuda()                         # the file records f16x2; the context's own precision wins
+    assert m4.load_flat_file(good) > 500
+    with torch.no_grad():
+        o4, _ = m4(frames[1].cuda())
+    assert float((o4 - o).abs().max()) / float(o.abs().max()) < 1e-4
