@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--torch-rocm-port", dest="torch_rocm_port", action="store_true", help=argparse.SUPPRESS)      # (round-6 scripts pass it explicitly)
     ap.set_defaults(torch_rocm_port=True)
     ap.add_argument("--torch-rocm-port-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect the HBM-side traffic of the dominant kernel class in this run (two child passes of "
+                    "`rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE` over a 3-step run of this script, ~70 s; N = 1 and without --no-extras only); "
+                    "`roofline.traffic` then replays the committed passes under profiles/")
     ap.add_argument("--launch-check", action="store_true", help="only rendezvous (gloo on CPU, RCCL on GPUs) and report the world size")
     return ap.parse_args()
 
@@ -137,6 +140,50 @@ def torch_rocm_port_child(args):
             out[name] = {"error": repr(e)[:300]}
     print(json.dumps(out), flush=True)
     sys.exit(0)
+
+
+def measure_pmc_traffic(args, H, W):
+    """HBM-side bytes per launch of the GEMM class of `args.precision`, measured by THIS run: two SEPARATE `rocprofv3 --kernel-trace --pmc <counter>` passes
+    (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: separate passes, KiB units, FETCH_SIZE doubled on gfx950) over a 3-step child run of this script, aggregated per
+    kernel class exactly like tools/pmc_traffic.py.  -> (bytes per launch | None, detail dict)"""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, {"error": "rocprofv3 not on PATH"}
+    base = tempfile.mkdtemp(prefix="uni_pmc_", dir="/tmp")
+    per, t0 = {}, time.perf_counter()
+    try:
+        for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            d = os.path.join(base, tag)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-extras", "--no-single-frame", "--no-pmc", "--model", args.model, "--height", str(H), "--width", str(W),
+                   "--batch", str(args.batch), "--precision", args.precision, "--task", args.task]
+            cp = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                                timeout=float(os.environ.get("UNI_BENCH_PMC_TIMEOUT", "240")))
+            dbs = glob.glob(d + "/**/*results.db", recursive=True)
+            if cp.returncode != 0 or not dbs:
+                return None, {"error": "rocprofv3 pass %s failed (rc %d): %s" % (ctr, cp.returncode, (cp.stderr or cp.stdout)[-200:])}
+            tot, n = 0.0, 0
+            for f in dbs:
+                for name, cname, val in sqlite3.connect(f).execute("select kernel_name, counter_name, value from counters_collection"):
+                    k = name.split("(")[0]
+                    hit = ("gemm_h2" in k or "mlp_fused" in k) if args.precision == "f16x2" else ("gemm_bf16" in k if args.precision == "bf16" else "gemm_f32" in k)
+                    if cname == ctr and hit:
+                        tot += float(val) * 1024.0 * (2.0 if tag == "fetch" else 1.0)
+                        n += 1
+            per[tag] = (tot / max(n, 1), n)
+    except Exception as e:                          # noqa: BLE001 -- a measurement aid must not take the bench line down
+        return None, {"error": repr(e)[:200]}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    if not per.get("fetch", (0, 0))[1] or not per.get("write", (0, 0))[1]:
+        return None, {"error": "no GEMM-class rows in the counter passes"}
+    return round(per["fetch"][0] + per["write"][0]), {"fetch_bytes_per_launch": round(per["fetch"][0]), "write_bytes_per_launch": round(per["write"][0]),
+                                                      "launches_counted": [per["fetch"][1], per["write"][1]], "seconds": round(time.perf_counter() - t0, 1),
+                                                      "method": "two separate child passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE -- bench.py --steps 3 --warmup 1 "
+                                                                "(FETCH_SIZE x 2: gfx950 correction; KiB units)"}
 
 
 def rccl_probe_child():
@@ -727,6 +774,13 @@ def main():
             traffic = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
         except Exception:
             tsrc = None
+        pmc_live = None
+        if world == 1 and not args.no_pmc and not args.no_extras:      # measured by this run (the replayed value stays as `traffic_replayed`)
+            torch.cuda.synchronize()
+            live, pmc_live = measure_pmc_traffic(args, H, W)
+            if live is not None:
+                pmc_live["replayed_from_profiles"] = {"bytes_per_launch": traffic, "source": tsrc}
+                traffic, tsrc = live, "this run"
         kname = {"bf16": "gemm_bf16_kernel / gemm_bf16_p44_kernel", "f16x2": "gemm_h2q_kernel / gemm_h2_kernel", "fp32": "gemm_f32_kernel"}[args.precision]
         roof = {"kernel": kname + " (all instantiations)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -736,8 +790,9 @@ def main():
                 # sustained shader clock / board power during the timed loop (sysfs) and the same rate against the MFMA peak AT THAT CLOCK
                 "clocks": clocks,
                 "frac_vs_peak_at_sustained_clock": round(ach / (peak * clocks["sclk_mhz_median"] / 2400.0), 4) if clocks else None,
-                "traffic": traffic, "traffic_source": tsrc, "traffic_measured_in_run": False,
-                "traffic_note": "HBM bytes per launch replayed from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/), not collected in this run",
+                "traffic": traffic, "traffic_source": tsrc, "traffic_measured_in_run": tsrc == "this run", "traffic_detail": pmc_live,
+                "traffic_note": ("HBM-side bytes per launch of the GEMM class from two separate rocprofv3 --pmc passes spawned by this run" if tsrc == "this run" else
+                                 "HBM bytes per launch replayed from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/), not collected in this run"),
                 "peak_note": "dense 16-bit MFMA 2500 TFLOP/s / %d MFMAs per fp32-equivalent product" % mfma_per_product if mfma_per_product > 1 else "dense MFMA peak of the dtype",
                 "mfma_per_product": mfma_per_product, "mfma_issue_TFLOPs": round(ach * mfma_per_product, 1),
                 "algorithmic_bytes_per_launch": round(g["bytes"] / max(g["launches"], 1)),
